@@ -1,0 +1,162 @@
+"""Generate tests/golden/*.npz by RUNNING THE IMPORTED REFERENCE (build container only).
+
+    python oracle/make_golden.py
+
+The reference has no tests or golden vectors, so these files are the parity pin:
+inputs + the reference's own outputs, small enough to commit. The reference never travels;
+the fixtures and this script do. Fixture ids follow SURVEY.md 8c (G1..G7).
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+from _refimport import inject_table, load, make_oracle_OD  # noqa: E402
+from radtxfr_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def save(name, **arrs):
+    p = os.path.join(OUT, name)
+    np.savez_compressed(p, **arrs)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(p) / 1024))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rt, hapi, ils_gauss = load()
+    atm = synthetic.load_standard_atmosphere()
+
+    # ---- G1 planckian -----------------------------------------------------------------
+    X = np.linspace(500, 6000, 56)
+    T32 = atm[:32, 5]
+    Xum = np.linspace(7.5, 13.5, 25)
+    T2d = np.array([[250.0, 275.0, 300.0], [216.65, 288.15, 320.0]])
+    save("g1_planck.npz", X=X, T32=T32, L32=rt.planckian(X, T32),
+         Ls=rt.planckian(X, 296.0), Xum=Xum, Lum=rt.planckian(Xum, T32[:5], wavelength=True),
+         T2d=T2d, L2d=rt.planckian(X, T2d),
+         spot=np.array([rt.planckian(500, 296)[0], *rt.planckian(1000, [250, 300])[0],
+                        rt.planckian(10.0, 300, wavelength=True)[0]]),
+         BT=rt.brightnessTemperature(X, rt.planckian(X, T32)),
+         BTum=rt.brightnessTemperature(Xum, rt.planckian(Xum, T32[:5], wavelength=True), wavelength=True),
+         L_bt2l=rt.BT2L(X, np.tile(T32[None, :8], (X.size, 1))))
+
+    # ---- G2 complex probability function / Voigt profile ---------------------------------
+    xs = np.concatenate([np.linspace(-20, 20, 81), [14.9, 14.99, 15.0, 15.01, -14.95]])
+    ys = np.array([1e-4, 1e-2, 0.1, 0.5, 1.0, 3.0, 8.0, 14.0, 14.999, 15.0, 25.0, 60.0])
+    xg, yg = np.meshgrid(xs, ys, indexing="ij")
+    wr, wi = hapi.hum1_wei(xg.ravel().copy(), yg.ravel().copy())
+    sg = np.array([999, 999.9, 1000, 1000.05, 1003.5])
+    pv = hapi.PROFILE_VOIGT(1000, 0.0009, 0.07, sg)[0]
+    sg2 = np.linspace(2349.0, 2351.0, 401)
+    pv2 = hapi.PROFILE_VOIGT(2350.0123, 0.0022, 0.004, sg2)[0]
+    # Weideman-24 coefficients exactly as the reference rebuilds them per call (:9816-9824)
+    N = 24
+    M_ = 2 * N
+    k = np.arange(-M_ + 1, M_)
+    L = np.sqrt(N / np.sqrt(2))
+    t = L * np.tan(k * np.pi / M_ / 2)
+    f = np.zeros(len(t) + 1)
+    f[1:] = np.exp(-t ** 2) * (L ** 2 + t ** 2)
+    a = np.flipud(np.real(np.fft.fft(np.fft.fftshift(f)))[1:N + 1] / (2 * M_))
+    save("g2_cpf_voigt.npz", x=xg.ravel(), y=yg.ravel(), wr=wr, wi=wi, sg=sg, pv=pv, sg2=sg2, pv2=pv2,
+         w24=a, L24=np.array(L))
+
+    # ---- G3 TIPS ------------------------------------------------------------------------
+    mis = [(1, 1), (1, 2), (2, 1), (2, 2), (3, 1)]
+    Ts = np.concatenate([T32, [296.0, 70.0, 84.9, 85.0, 2990.0, 3000.0]])
+    Q = np.array([[hapi.PYTIPS(m, i, float(tt)) for tt in Ts] for (m, i) in mis])
+    Sx = hapi.EnvironmentDependency_Intensity(1e-21, 250., 296., hapi.PYTIPS(1, 1, 250.), hapi.PYTIPS(1, 1, 296.), 500., 1000.)
+    save("g3_tips.npz", mi=np.array(mis), T=Ts, Q=Q, S_spot=np.array(Sx))
+
+    # ---- G4 absorptionCoefficient_Voigt, 2000-line table, C2 grid --------------------------
+    tbl = synthetic.synth_line_table(synthetic.SEED_C2, 2000, 675.0, 1425.0)
+    inject_table(hapi, "g4", tbl)
+    grid = np.linspace(700, 1400, 70000)
+    out = {}
+    for tag, row in (("l01", 0), ("l32", 31)):
+        Tk, pk = float(atm[row, 5]), float(atm[row, 4]) / 101325.0
+        _, xs_ = quiet(hapi.absorptionCoefficient_Voigt, SourceTables="g4", Environment={"T": Tk, "p": pk},
+                       OmegaGrid=grid, HITRAN_units=True)
+        out["T_" + tag], out["p_" + tag], out["xs_" + tag] = Tk, pk, xs_
+    # options exercised: explicit Components with custom abundance, self-broadening, HITRAN_units=False, wings
+    _, xs_opt = quiet(hapi.absorptionCoefficient_Voigt, Components=[(1, 1), (2, 1, 0.5)], SourceTables="g4",
+                      Environment={"T": 250.0, "p": 0.4}, OmegaGrid=grid[20000:30000], HITRAN_units=False,
+                      GammaL="gamma_self", OmegaWing=2.0, OmegaWingHW=20.0)
+    _, xs_dil = quiet(hapi.absorptionCoefficient_Voigt, SourceTables="g4", Environment={"T": 230.0, "p": 0.05},
+                      OmegaGrid=grid[40000:46000], Diluent={"air": 0.7, "self": 0.3})
+    save("g4_voigt_xsec.npz", seed=synthetic.SEED_C2, n_lines=2000, nu_lo=675.0, nu_hi=1425.0,
+         grid_lo=700.0, grid_hi=1400.0, grid_n=70000, xs_opt=xs_opt, xs_dil=xs_dil,
+         **{k_: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k_, v in out.items()})
+
+    # ---- G5 per-layer OD + compute_TUD on 3 windows x 32 layers ---------------------------
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    a32 = synthetic.c3_atmosphere(32)
+    g5 = {}
+    for w, (xlo, xhi) in enumerate([(500.0, 502.0), (2349.0, 2351.0), (5998.0, 6000.0)]):
+        sub = synthetic.subset_table(full, xlo - 12.0, xhi + 12.0)
+        name = "g5w%d" % w
+        inject_table(hapi, name, sub)
+        rt.compute_OD = make_oracle_OD(hapi, name, sub)
+        opts = dict(DVOUT=0.001, Zs=a32["Zs"], Ts=a32["Ts"], Ps=a32["Ps"], PLs=a32["PLs"], MFs_VAL=a32["MFs_VAL"],
+                    MFs_ID=a32["MFs_ID"], theta_r=0, N_angle=30, Altitudes=np.asarray([500]), save=True, returnOD=False)
+        cwd = os.getcwd()
+        os.chdir("/tmp")
+        try:
+            Xw, tau, Lu, Ld = quiet(rt.compute_TUD, xlo, xhi, **opts)
+            dump = np.load("/tmp/ComputeTUD.npz")
+            OD = dump["OD"]
+        finally:
+            os.chdir(cwd)
+        g5.update({f"w{w}_lo": xlo, f"w{w}_hi": xhi, f"w{w}_X": Xw, f"w{w}_tau": tau, f"w{w}_Lu": Lu,
+                   f"w{w}_Ld": Ld, f"w{w}_OD": OD})
+        if w == 1:
+            # quirk coverage: slant path, several sensor altitudes, returnOD, fewer angles
+            o2 = dict(opts, theta_r=0.6, Altitudes=np.asarray([1.0, 4.05, 9.0]), N_angle=7, save=False)
+            _, tau2, Lu2, Ld2 = quiet(rt.compute_TUD, xlo, xhi, **o2)
+            o3 = dict(opts, Altitudes=np.asarray([9.0]), returnOD=True, save=False)
+            _, tau3, Lu3, Ld3 = quiet(rt.compute_TUD, xlo, xhi, **o3)
+            g5.update(w1_tau_alt=tau2, w1_Lu_alt=Lu2, w1_Ld_alt=Ld2, w1_tau_rod=tau3, w1_Lu_rod=Lu3, w1_Ld_rod=Ld3)
+    save("g5_tud_windows.npz", seed=synthetic.SEED_C3, n_lines=100000, nu_lo=475.0, nu_hi=6025.0, pad=12.0, **g5)
+
+    # ---- G6 apparent radiance --------------------------------------------------------------
+    rng = np.random.default_rng(7)
+    nX, nE, nA = 128, 9, 3
+    Xb = np.sort(1e4 / np.linspace(7.6, 13.1, nX))
+    emis = rng.uniform(0.6, 0.99, (nX, nE))
+    Tsurf = np.array([280.0, 287.87, 301.5])
+    tau = rng.uniform(0.2, 0.98, (nX, nA))
+    La = rng.uniform(0.5, 4.0, (nX, nA))
+    Ld = rng.uniform(1.0, 8.0, (nX, nA))
+    dT = np.arange(-10, 10.5, 2.5)
+    L0 = rt.compute_LWIR_apparent_radiance(Xb, emis, Tsurf, tau, La, Ld)
+    L1, Ls1 = rt.compute_LWIR_apparent_radiance(Xb, emis, Tsurf, tau, La, Ld, dT=dT, return_Ls=True)
+    save("g6_apparent_radiance.npz", X=Xb, emis=emis, Ts=Tsurf, tau=tau, La=La, Ld=Ld, dT=dT, L0=L0, L1=L1, Ls1=Ls1)
+
+    # ---- G7 ILS ---------------------------------------------------------------------------
+    Xh = np.linspace(740.0, 1340.0, 24000)
+    Y1 = 5 + np.sin(Xh / 7.0) + 0.3 * np.cos(Xh * 3.1)
+    Y2 = np.stack([Y1, np.exp(-((Xh - 1000) / 80.0) ** 2), rng.uniform(0, 1, Xh.size)], axis=1)
+    xo1, yo1 = rt.ILS_MAKO(Xh, Y1)
+    xo2, yo2 = rt.ILS_MAKO(Xh, Y2)
+    xo3, yo3 = rt.ILS_MAKO(Xh, Y2, resFactor=2)
+    yo4 = rt.ILS_MAKO(Xh, Y2, returnX=False, fwhm_sf=1.3, shift=0.4, scale=1.0005)
+    xg1, yg1 = ils_gauss.ILS_MAKO(Xh, Y1)
+    xg2, yg2 = ils_gauss.ILS_MAKO(Xh, Y2)
+    save("g7_ils.npz", X_lo=740.0, X_hi=1340.0, X_n=24000, Y2=Y2.astype(np.float64), xo1=xo1, yo1=yo1, xo2=xo2,
+         yo2=yo2, xo3=xo3, yo3=yo3, yo4=yo4, xg1=xg1, yg1=yg1, xg2=xg2, yg2=yg2)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Synthetic HITRAN-format inputs.
+
+No HITRAN line data and no AER TAPE3 exist offline, so parity and benchmarks use
+synthetic line tables with the column set and the `.par` field precision of the
+reference's line-table type (misc/hapi.py:468-559: nu %12.6f, sw %10.3E,
+gamma_air %5.4f, gamma_self %5.3f, elower %10.4f, n_air %4.2f, delta_air %8.6f).
+The same table feeds the oracle and the HIP engine.
+"""
+import os
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+# seeds fixed by SURVEY.md section 8d
+SEED_C2 = 20261004
+SEED_C3 = 20261005
+SEED_C4 = 20261006
+SEED_C5 = 42
+
+
+def synth_line_table(seed, n_lines, nu_lo, nu_hi):
+    """Columns as numpy arrays, sorted by nu; values rounded to .par precision."""
+    rng = np.random.default_rng(seed)
+    nu = np.sort(rng.uniform(nu_lo, nu_hi, n_lines))
+    molec = rng.integers(1, 3, n_lines)  # 1 = H2O, 2 = CO2, p = 1/2 each
+    iso = np.where(rng.random(n_lines) < 0.9, 1, 2)
+    sw = 10.0 ** rng.uniform(-27.0, -19.0, n_lines)
+    elower = rng.uniform(0.0, 3000.0, n_lines)
+    gamma_air = rng.uniform(0.03, 0.11, n_lines)
+    gamma_self = rng.uniform(0.1, 0.5, n_lines)
+    n_air = rng.uniform(0.4, 0.8, n_lines)
+    delta_air = rng.uniform(-0.01, 0.002, n_lines)
+    nu = np.sort(np.round(nu, 6))
+    sw = np.array([float("%10.3E" % v) for v in sw])
+    return {
+        "molec_id": molec.astype(np.int64),
+        "local_iso_id": iso.astype(np.int64),
+        "nu": nu,
+        "sw": sw,
+        "elower": np.round(elower, 4),
+        "gamma_air": np.round(gamma_air, 4),
+        "gamma_self": np.round(gamma_self, 3),
+        "n_air": np.round(n_air, 2),
+        "delta_air": np.round(delta_air, 6),
+    }
+
+
+def subset_table(tbl, lo, hi):
+    """Rows with lo <= nu <= hi (a line farther than its wing cutoff cannot contribute)."""
+    m = (tbl["nu"] >= lo) & (tbl["nu"] <= hi)
+    return {k: v[m] for k, v in tbl.items()}
+
+
+def load_standard_atmosphere():
+    """66-row 1976 US-Std table: N,Z0,Z1,PL,P,T,H2O,CO2,O3,N2O,CO,CH4,O2,N2,Ar
+    (copy of the reference's StandardAtmosphere.csv input fixture)."""
+    return np.loadtxt(os.path.join(_DATA, "StandardAtmosphere.csv"), delimiter=",", skiprows=1)
+
+
+def c3_atmosphere(n_layers=32):
+    """Rows 1..n_layers of the CSV: the '32-layer' column of configs C3-C5 (0-9.5 km)."""
+    A = load_standard_atmosphere()[:n_layers]
+    return {
+        "Zs": A[:, 1].copy(), "Ts": A[:, 5].copy(), "Ps": A[:, 4].copy(), "PLs": A[:, 3].copy(),
+        "MFs_VAL": A[:, 6:8].copy() * 1e6,  # H2O, CO2 [ppmv]
+        "MFs_ID": np.array([1, 2]),
+    }
+
+
+def synth_emissivities(seed=SEED_C4, n_emis=2000):
+    """C4 emissivity set on the ASTER-DB knot axis: returns (X_e, emis[nK, nE])."""
+    rng = np.random.default_rng(seed)
+    X_e = np.linspace(1e4 / 14.5, 1e4 / 6.75, 791)
+    P = rng.uniform(40.0, 400.0, n_emis)
+    phi = rng.uniform(0.0, 2 * np.pi, n_emis)
+    e = 0.85 + 0.1 * np.sin(2 * np.pi * X_e[:, None] / P[None, :] + phi[None, :]) \
+        + 0.02 * rng.standard_normal((X_e.size, n_emis))
+    return X_e, np.clip(e, 1e-4, 1 - 1e-4)
