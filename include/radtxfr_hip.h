@@ -1,0 +1,156 @@
+/*
+ * radtxfr_hip.h -- C ABI of libradtxfr_hip.so, the MI355X (gfx950) engine behind the
+ * reference's Python hot-path functions.
+ *
+ * The reference (westi024/RadTxfr) is 100 % Python and has no FFI of its own; its boundary for
+ * this path is the set of Python call signatures listed in SURVEY.md section 8b. Each entry point
+ * below is what a binding for one of those functions calls; the cited lines are the reference
+ * code the entry point replaces. radtxfr_amd/_lib.py is the ctypes binding; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; rtx_last_error() gives the text
+ *     (thread-local). No C++ exception crosses the ABI.
+ *   - pointers are DEVICE pointers unless the name ends in _h (host).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Calls are asynchronous
+ *     with respect to the host and never allocate, free or synchronise, except the
+ *     rtx_lines_* / rtx_prep_* create/free calls, which say so.
+ *   - spectra are float32, wavenumber-contiguous; a layer-resolved array is layer-major
+ *     ([n_layers][ld], element (k,i) at k*ld+i) so loads along the wavenumber axis coalesce.
+ *   - the spectral grid is never materialised: X[i] = xmin + (offset+i)*step in fp64 (product
+ *     then sum, unfused, as np.linspace builds it) and X[n_total-1] = xmax exactly.
+ */
+#ifndef RADTXFR_HIP_H
+#define RADTXFR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* Uniform spectral axis = np.linspace(xmin, xmax, n_total) as built by
+ * radiative_transfer.py:251-271 (make_spectral_axis); [offset, offset+n) is the part this
+ * call (this GPU) owns, so a wavenumber shard evaluates bit-identical grid values. */
+typedef struct rtx_grid {
+  double xmin;
+  double xmax;
+  double step; /* (xmax-xmin)/(n_total-1), the value np.linspace computes */
+  int64_t n_total;
+  int64_t offset;
+  int64_t n;
+} rtx_grid;
+
+int rtx_version(void);
+const char* rtx_last_error(void);
+/* name[0..len) <- device name, *n_cu <- compute units, of the current HIP device */
+int rtx_device_info(char* name_h, int len, int* n_cu_h);
+
+/* ------------------------------------------------------------------------------------------
+ * Line table. Replaces LOCAL_TABLE_CACHE[name]['data'] (misc/hapi.py:438-463) for the columns
+ * absorptionCoefficient_Voigt reads (misc/hapi.py:11059-11125). Rows must be sorted by nu.
+ * `species_h[l]` in [0,n_species) indexes the caller's list of distinct (molec_id,local_iso_id)
+ * pairs; the per-species quantities of rtx_line_prep are given in that order.
+ * n_self_h / deltap_air_h / delta_self_h may be NULL (hapi's fallbacks apply: n_self->n_air,
+ * others 0; misc/hapi.py:11097-11125). Allocates device memory and synchronises. */
+typedef struct rtx_lines rtx_lines;
+int rtx_lines_create(int64_t n_lines, int n_species, const double* nu_h, const double* sw_h,
+                     const double* elower_h, const double* gamma_air_h, const double* gamma_self_h,
+                     const double* n_air_h, const double* n_self_h, const double* delta_air_h,
+                     const double* deltap_air_h, const double* delta_self_h,
+                     const int32_t* species_h, rtx_lines** out);
+int rtx_lines_free(rtx_lines* lines);
+int64_t rtx_lines_count(const rtx_lines* lines);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-(line, layer) prologue, fp64. Replaces the per-line environment block of
+ * absorptionCoefficient_Voigt, misc/hapi.py:11068-11134: S(T) (:10169-10175), GammaD (:11085-
+ * 11087), Gamma0 (:10183-10184), Shift0 (:11127-11128), OmegaWingF (:11131) and the two
+ * bisect() window bounds (:11133-11134), for every line and every layer at once.
+ *
+ * Host inputs (small, copied with hipMemcpyAsync on `stream`; kept alive by the prep object):
+ *   T_h[n_layers] K, p_atm_h[n_layers] atm
+ *   qratio_h[n_species*n_layers]   Q(Tref)/Q(T_k) per species (TIPS, misc/hapi.py:11069-11070)
+ *   weight_h[n_species*n_layers]   factor multiplying S(T) for that species in that layer:
+ *       hapi path : factor/natural_abundance*abundance  (misc/hapi.py:11136-11137)
+ *       OD path   : volumeConcentration(p,T)*x_m*PL*1e5  (SURVEY 8(a-3)); 0 drops the species
+ *   mass_h[n_species]  g/mol (misc/hapi.py:11086)
+ *   dil_air, dil_self  Diluent fractions (misc/hapi.py:11025-11032)
+ *   omega_wing, omega_wing_hw  (misc/hapi.py:11131); intensity_threshold (:11082)
+ *   scale  power of two folded into the fp32 strengths (HITRAN-unit cross sections are ~1e-25)
+ * rtx_prep_create allocates (n_lines*max_layers records, plus per-tile line ranges for grids of up
+ * to max_points points) and may synchronise; rtx_line_prep only enqueues work. One prep object
+ * can be re-used for any atmospheric state / grid within its capacity. */
+typedef struct rtx_prep rtx_prep;
+int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t max_points, rtx_prep** out);
+int rtx_prep_free(rtx_prep* prep);
+int rtx_line_prep(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, int n_layers,
+                  const double* T_h, const double* p_atm_h, const double* qratio_h,
+                  const double* weight_h, const double* mass_h, double dil_air, double dil_self,
+                  double omega_wing, double omega_wing_hw, double intensity_threshold,
+                  double scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Voigt line-sum. Replaces the per-line PROFILE_VOIGT + scatter-add loop, misc/hapi.py:11050,
+ * 11135-11138 (PROFILE_VOIGT :10131 -> pcqsdhc PART1 :9900-9915 -> hum1_wei :9833-9844) with a
+ * gather over the lines whose window covers each grid point.
+ *   out_f32[n_layers][ld]  (may be NULL)   sum * 1            -> layer optical depths / k(nu)
+ *   out_f64[n_layers][ld]  (may be NULL)   (double)sum/scale  -> hapi Xsect
+ * compute_OD contract: radiative_transfer.py:395-456. */
+/* points per line-sum workgroup tile (capacity granularity of rtx_prep_create) */
+int rtx_voigt_tile_points(void);
+int rtx_voigt_sum(const rtx_prep* prep, const rtx_grid* grid, int n_layers, float* out_f32,
+                  double* out_f64, int64_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Planck radiance. Replaces planckian(), radiative_transfer.py:792-848.
+ *   X == NULL : spectral axis = grid; else X[nx] (fp64 wavenumbers or micrometres)
+ *   out[nx][nT] float64 (C order, spectral axis first, as the reference returns it) */
+int rtx_planck(const rtx_grid* grid, const double* X, int64_t nx, const double* T, int64_t nT,
+               int wavelength, double* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TUD integration. Replaces the body of compute_TUD after the OD loop,
+ * radiative_transfer.py:340-392: on-the-fly Planck, tau, upwelling recurrence (:346-356),
+ * N_angle-stream downwelling recurrence and its cos*sin average (:368-389).
+ *   OD[n_layers][ld] float32;  T_h[n_layers];
+ *   n_alt sensor altitudes: mask_h[a*n_layers+k] = (Z[k] <= zs[a]) (:348), count = popcount;
+ *   n_mu slant factors mu_h (:313);  n_down = layers the downwelling loop covers (quirk: the
+ *   count of the LAST altitude, :353,370);
+ *   outputs: tau[n_alt*n_mu][ld_out], Lu[n_alt*n_mu][ld_out] (index a*n_mu+m), Ld[ld_out];
+ *   Ld_angles: NULL, or [n_angle][ld_out] per-stream downwelling radiances (what opts['save']
+ *   dumps as Ld, :374-386);
+ *   return_od != 0 puts sum(OD*mu) in the tau slot (:349-350). */
+int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_layers, const double* T_h,
+            int n_alt, const uint8_t* mask_h, int n_mu, const double* mu_h, int n_down,
+            int n_angle, int return_od, float* tau, float* Lu, float* Ld, float* Ld_angles,
+            int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * At-sensor radiance. Replaces compute_LWIR_apparent_radiance(), radiative_transfer.py:1017-
+ * 1069: L = tau*(emis*B(Ts+dT) + (1-emis)*Ld) + La.
+ *   X[nX] fp64; emis[nX][nE]; Ts[nA] fp64; tau,La,Ld [nX][nA]; dT[nT] fp64 or NULL (nT=0)
+ *   L [nX][nE][nA][max(nT,1)], Ls same shape or NULL. All spectra float32 (the reference's
+ *   own caller casts to float32 first: Compute_LWIR_Apparent_Radiance.py:9-20). */
+int rtx_apparent_radiance(const double* X, int64_t nX, const float* emis, int64_t nE,
+                          const double* Ts, int64_t nA, const float* tau, const float* La,
+                          const float* Ld, const double* dT, int64_t nT, float* L, float* Ls,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MAKO instrument line shape. Replaces ILS_MAKO (triangle), radiative_transfer.py:1236-1256
+ * (kind 0) and the Gaussian ILS_MAKO.py:21-33 (kind 1): Y_out[b][s] = sum_i w_b(X_i) Y[i][s] /
+ * sum_i w_b(X_i). Band centres/widths are computed by the caller (host, :1226-1241) and passed:
+ *   centre[nB] (= scale*X_out+shift), sigma[nB]: fp64 DEVICE arrays;
+ *   Y [nx][nS] float32 (spectral axis first, as the reference lays it out), ldY = row stride;
+ *   Y_out [nB][nS] float32. X == NULL -> uniform grid, else explicit fp64 axis (ascending). */
+int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t nx, const float* Y,
+            int64_t nS, int64_t ldY, int nB, const double* centre, const double* sigma,
+            float* Y_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADTXFR_HIP_H */

@@ -38,6 +38,12 @@ def main():
     rt, hapi, ils_gauss = load()
     atm = synthetic.load_standard_atmosphere()
 
+    # ---- G0 module defaults (embedded StdAtmos table and the options built from it) ---------
+    save("g0_defaults.npz", StdAtmos=rt.StdAtmos, Zs=rt.options["Zs"], Ts=rt.options["Ts"], Ps=rt.options["Ps"],
+         PLs=rt.options["PLs"], MFs_VAL=rt.options["MFs_VAL"], MFs_ID=rt.options["MFs_ID"],
+         DVOUT=rt.options["DVOUT"], N_angle=rt.options["N_angle"], Altitudes=rt.options["Altitudes"],
+         c1=rt.c1, c2=rt.c2)
+
     # ---- G1 planckian -----------------------------------------------------------------
     X = np.linspace(500, 6000, 56)
     T32 = atm[:32, 5]

@@ -1,0 +1,87 @@
+// Internal definitions shared by the HIP translation units of libradtxfr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/radtxfr_hip.h"
+
+// ---- error plumbing (thread-local text behind rtx_last_error) ---------------------------------
+void rtx_set_error(const char* fmt, ...);
+#define RTX_FAIL(...)          \
+  do {                         \
+    rtx_set_error(__VA_ARGS__); \
+    return 1;                  \
+  } while (0)
+#define RTX_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) RTX_FAIL("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+#define RTX_LAUNCH_CHECK()                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = hipGetLastError();                                                       \
+    if (e_ != hipSuccess) RTX_FAIL("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- device-side view of the spectral grid ------------------------------------------------------
+struct GridDev {
+  double xmin, xmax, step;
+  long long n_total, offset, n;
+};
+static inline GridDev to_dev(const rtx_grid* g) {
+  GridDev d;
+  d.xmin = g->xmin; d.xmax = g->xmax; d.step = g->step;
+  d.n_total = g->n_total; d.offset = g->offset; d.n = g->n;
+  return d;
+}
+int rtx_check_grid(const rtx_grid* g);
+
+// X[ig] for a GLOBAL index exactly as np.linspace builds it: arange*step + start (two roundings,
+// never fused), last point pinned to xmax. Indices outside [0,n_total) extrapolate.
+__device__ __forceinline__ double grid_x(const GridDev& g, long long ig) {
+  double v = __dadd_rn(__dmul_rn((double)ig, g.step), g.xmin);
+  return (ig == g.n_total - 1) ? g.xmax : v;
+}
+
+// ---- per-(line,layer) records written by the prologue, read by the line-sum --------------------
+// fp32 record (32 B): everything the asymptotic (far-wing) evaluation needs, relative to the grid.
+struct __attribute__((aligned(16))) LineRec {
+  float a;   // x per grid index = step*cte,  cte = sqrt(ln2)/GammaD
+  float c;   // x at grid index i0            = (X[i0]-nu0')*cte
+  float y;   // Gamma0*cte
+  float A;   // weight*S(T)*cte/sqrt(pi)*scale  (strength times the profile's prefactor)
+  int i0;    // LOCAL grid index nearest to the shifted centre nu0' (may lie outside [0,n))
+  int lo;    // window = local indices [lo,hi): bisect(X,nu0-W), bisect(X,nu0+W) clipped to the shard
+  int hi;
+  int zw;    // half-width, in grid points, of the band around i0 that can hold |x|+y<15 (0: none)
+};
+// fp64 companion (32 B), read only where the Weideman region is entered.
+struct __attribute__((aligned(16))) LineRec64 {
+  double sg0;  // nu0 + Shift0
+  double cte;
+  double y;
+  double A;
+};
+
+struct rtx_lines {
+  long long n;
+  int n_species;
+  double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
+  int* species;
+};
+
+struct rtx_prep {
+  long long n_lines;
+  int max_layers;
+  int n_layers;        // of the last rtx_line_prep
+  LineRec* rec;        // [max_layers][n_lines]
+  LineRec64* rec64;    // [max_layers][n_lines]
+  int* ic;             // [n_lines] local grid index nearest the UNSHIFTED centre (sorted)
+  int* maxhw;          // [max_layers] max window half-width in grid points (+margin)
+  int2* ranges;        // [max_layers][max_tiles] candidate line range per line-sum tile
+  long long max_tiles;
+  double* env;         // device copy of T,p,qratio,weight,mass (packed)
+  size_t env_cap;
+  double scale;
+};

@@ -1,0 +1,339 @@
+// Line table upload + the fp64 per-(line,layer) prologue kernel.
+//
+// Replaces the per-line environment block of hapi.absorptionCoefficient_Voigt
+// (reference misc/hapi.py:11068-11134) -- S(T), GammaD, Gamma0, Shift0, OmegaWingF and the two
+// bisect() window bounds -- for all lines x all layers in one launch. fp64 throughout, operations
+// in the reference's order, so the hard wing cutoff lands on the same grid points.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "rtx_common.h"
+
+// ---- error text ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void rtx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* rtx_last_error(void) { return g_err; }
+extern "C" int rtx_version(void) { return RTX_VERSION; }
+extern "C" int rtx_device_info(char* name_h, int len, int* n_cu_h) {
+  int dev;
+  RTX_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  RTX_HIP(hipGetDeviceProperties(&p, dev));
+  if (name_h && len > 0) snprintf(name_h, len, "%s (%s)", p.name, p.gcnArchName);
+  if (n_cu_h) *n_cu_h = p.multiProcessorCount;
+  return 0;
+}
+
+int rtx_check_grid(const rtx_grid* g) {
+  if (!g) RTX_FAIL("grid is NULL");
+  if (g->n_total < 2) RTX_FAIL("grid needs at least 2 points (n_total=%lld)", (long long)g->n_total);
+  if (!(g->step > 0.0)) RTX_FAIL("grid step must be > 0 (ascending axis)");
+  if (g->offset < 0 || g->n < 0 || g->offset + g->n > g->n_total)
+    RTX_FAIL("grid shard [%lld,+%lld) outside [0,%lld)", (long long)g->offset, (long long)g->n, (long long)g->n_total);
+  if (g->n_total > 2000000000LL) RTX_FAIL("grid too long for 32-bit point indices");
+  return 0;
+}
+
+// ---- line table ------------------------------------------------------------------------------------
+static int upload(double** dst, const double* src_h, long long n, bool zero_if_null) {
+  *dst = nullptr;
+  if (!src_h && !zero_if_null) return 0;
+  RTX_HIP(hipMalloc((void**)dst, sizeof(double) * (size_t)(n > 0 ? n : 1)));
+  if (src_h)
+    RTX_HIP(hipMemcpy(*dst, src_h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  else
+    RTX_HIP(hipMemset(*dst, 0, sizeof(double) * (size_t)n));
+  return 0;
+}
+
+extern "C" int rtx_lines_free(rtx_lines* L) {
+  if (!L) return 0;
+  double* p[] = {L->nu, L->sw, L->elower, L->gamma_air, L->gamma_self, L->n_air, L->n_self, L->delta_air, L->deltap_air, L->delta_self};
+  for (double* q : p)
+    if (q) (void)hipFree(q);
+  if (L->species) (void)hipFree(L->species);
+  delete L;
+  return 0;
+}
+
+extern "C" int rtx_lines_create(int64_t n, int n_species, const double* nu_h, const double* sw_h, const double* elower_h,
+                                const double* gamma_air_h, const double* gamma_self_h, const double* n_air_h,
+                                const double* n_self_h, const double* delta_air_h, const double* deltap_air_h,
+                                const double* delta_self_h, const int32_t* species_h, rtx_lines** out) {
+  if (!out) RTX_FAIL("out is NULL");
+  *out = nullptr;
+  if (n < 0 || n > 2000000000LL) RTX_FAIL("bad line count %lld", (long long)n);
+  if (n_species < 1 || n_species > 4096) RTX_FAIL("n_species must be in [1,4096], got %d", n_species);
+  if (n > 0 && (!nu_h || !sw_h || !elower_h || !gamma_air_h || !gamma_self_h || !n_air_h || !delta_air_h || !species_h))
+    RTX_FAIL("a required line-table column is NULL");
+  for (int64_t i = 0; i < n; ++i) {
+    if (i > 0 && nu_h[i] < nu_h[i - 1]) RTX_FAIL("line table must be sorted by nu (row %lld)", (long long)i);
+    if (species_h[i] < 0 || species_h[i] >= n_species) RTX_FAIL("species index out of range at row %lld", (long long)i);
+  }
+  rtx_lines* L = new rtx_lines();
+  memset(L, 0, sizeof(*L));
+  L->n = n;
+  L->n_species = n_species;
+  int rc = 0;
+  rc |= upload(&L->nu, nu_h, n, true);
+  rc |= upload(&L->sw, sw_h, n, true);
+  rc |= upload(&L->elower, elower_h, n, true);
+  rc |= upload(&L->gamma_air, gamma_air_h, n, true);
+  rc |= upload(&L->gamma_self, gamma_self_h, n, true);
+  rc |= upload(&L->n_air, n_air_h, n, true);
+  rc |= upload(&L->n_self, n_self_h, n, false);
+  rc |= upload(&L->delta_air, delta_air_h, n, true);
+  rc |= upload(&L->deltap_air, deltap_air_h, n, false);
+  rc |= upload(&L->delta_self, delta_self_h, n, false);
+  if (!rc) {
+    hipError_t e = hipMalloc((void**)&L->species, sizeof(int) * (size_t)(n > 0 ? n : 1));
+    if (e == hipSuccess && n > 0) e = hipMemcpy(L->species, species_h, sizeof(int) * (size_t)n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      rtx_set_error("species upload failed: %s", hipGetErrorString(e));
+      rc = 1;
+    }
+  }
+  if (rc) {
+    rtx_lines_free(L);
+    return 1;
+  }
+  *out = L;
+  return 0;
+}
+extern "C" int64_t rtx_lines_count(const rtx_lines* L) { return L ? L->n : -1; }
+
+// ---- prep object -------------------------------------------------------------------------------------
+extern "C" int rtx_prep_free(rtx_prep* P) {
+  if (!P) return 0;
+  if (P->rec) (void)hipFree(P->rec);
+  if (P->rec64) (void)hipFree(P->rec64);
+  if (P->ic) (void)hipFree(P->ic);
+  if (P->maxhw) (void)hipFree(P->maxhw);
+  if (P->env) (void)hipFree(P->env);
+  if (P->ranges) (void)hipFree(P->ranges);
+  delete P;
+  return 0;
+}
+
+extern "C" int rtx_voigt_tile_points(void);
+
+extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t max_points, rtx_prep** out) {
+  if (!out) RTX_FAIL("out is NULL");
+  *out = nullptr;
+  if (!lines) RTX_FAIL("lines is NULL");
+  if (max_layers < 1 || max_layers > 4096) RTX_FAIL("max_layers must be in [1,4096]");
+  if (max_points < 1 || max_points > 2000000000LL) RTX_FAIL("max_points must be in [1,2e9]");
+  rtx_prep* P = new rtx_prep();
+  memset(P, 0, sizeof(*P));
+  P->n_lines = lines->n;
+  P->max_layers = max_layers;
+  size_t nrec = (size_t)(lines->n > 0 ? lines->n : 1) * (size_t)max_layers;
+  P->env_cap = (size_t)max_layers * (2 + 2 * (size_t)lines->n_species) + (size_t)lines->n_species;
+  const int tile = rtx_voigt_tile_points();
+  P->max_tiles = (max_points + tile - 1) / tile;
+  hipError_t e = hipMalloc((void**)&P->rec, nrec * sizeof(LineRec));
+  if (e == hipSuccess) e = hipMalloc((void**)&P->rec64, nrec * sizeof(LineRec64));
+  if (e == hipSuccess) e = hipMalloc((void**)&P->ic, sizeof(int) * (size_t)(lines->n > 0 ? lines->n : 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&P->maxhw, sizeof(int) * (size_t)max_layers);
+  if (e == hipSuccess) e = hipMalloc((void**)&P->env, sizeof(double) * P->env_cap);
+  if (e == hipSuccess) e = hipMalloc((void**)&P->ranges, sizeof(int2) * (size_t)P->max_tiles * (size_t)max_layers);
+  if (e != hipSuccess) {
+    rtx_set_error("rtx_prep_create: %s (%zu records)", hipGetErrorString(e), nrec);
+    rtx_prep_free(P);
+    return 1;
+  }
+  *out = P;
+  return 0;
+}
+
+// ---- prologue kernel --------------------------------------------------------------------------------
+// hapi constants (misc/hapi.py:84-92, :10171, :11085)
+#define H_CBOLTS 1.380648813e-16
+#define H_CC 2.99792458e10
+#define H_CMASSMOL 1.66053873e-27
+#define H_C2 1.4388028496642257
+#define H_TREF 296.0
+
+struct PrepArgs {
+  const double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
+  const int* species;
+  long long n_lines;
+  int n_layers, n_species;
+  const double *T, *p, *qratio, *weight, *mass;  // device copies of the small per-layer tables
+  double dil_air, dil_self, omega_wing, omega_wing_hw, thresh, scale;
+  GridDev g;
+  LineRec* rec;
+  LineRec64* rec64;
+  int* ic;
+  int* maxhw;
+};
+
+// bisect.bisect (= bisect_right) of value v on the FULL grid: number of grid points <= v.
+__device__ long long grid_bisect_right(const GridDev& g, double v) {
+  double t = (v - g.xmin) / g.step;
+  long long k;
+  if (!(t > -1.0)) k = 0;
+  else if (t >= (double)g.n_total) k = g.n_total;
+  else k = (long long)floor(t) + 1;
+  if (k < 0) k = 0;
+  if (k > g.n_total) k = g.n_total;
+  while (k < g.n_total && grid_x(g, k) <= v) ++k;
+  while (k > 0 && grid_x(g, k - 1) > v) --k;
+  return k;
+}
+
+__device__ __forceinline__ int clamp_local(long long ig, const GridDev& g) {
+  long long l = ig - g.offset;
+  if (l < 0) l = 0;
+  if (l > g.n) l = g.n;
+  return (int)l;
+}
+
+__device__ __forceinline__ int sat_i32(long long v) {
+  const long long M = 1000000000LL;  // keeps i - i0 and i0 +- zw well inside int32
+  return (int)(v < -M ? -M : (v > M ? M : v));
+}
+
+__global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  int my_hw = 0;
+  if (l < a.n_lines) {
+    const GridDev& g = a.g;
+    const double T = a.T[k], p = a.p[k];
+    const double nu = a.nu[l];
+    const int sp = a.species[l];
+    const double w = a.weight[(size_t)sp * a.n_layers + k];
+    // S(T): EnvironmentDependency_Intensity, misc/hapi.py:10169-10175 (SigmaTref/SigmaT = qratio)
+    const double el = a.elower[l];
+    const double ch = exp(-H_C2 * el / T) * (1.0 - exp(-H_C2 * nu / T));
+    const double zn = exp(-H_C2 * el / H_TREF) * (1.0 - exp(-H_C2 * nu / H_TREF));
+    const double S = a.sw[l] * a.qratio[(size_t)sp * a.n_layers + k] * ch / zn;
+    // GammaD, misc/hapi.py:11085-11087
+    const double m = a.mass[sp] * H_CMASSMOL * 1000.0;
+    const double GammaD = sqrt(2.0 * H_CBOLTS * T * log(2.0) / m / (H_CC * H_CC)) * nu;
+    // Gamma0 / Shift0 over the diluent mix, misc/hapi.py:11090-11128
+    double Gamma0 = 0.0, Shift0 = 0.0;
+    const double tr = H_TREF / T;
+    if (a.dil_air != 0.0) {
+      Gamma0 += a.dil_air * (a.gamma_air[l] * p / 1.0 * pow(tr, a.n_air[l]));
+      const double dp = a.deltap_air ? a.deltap_air[l] : 0.0;
+      Shift0 += a.dil_air * ((a.delta_air[l] + dp * (T - H_TREF)) * p / 1.0);
+    }
+    if (a.dil_self != 0.0) {
+      double ns = a.n_self ? a.n_self[l] : a.n_air[l];
+      if (a.n_self && ns == 0.0) ns = a.n_air[l];
+      Gamma0 += a.dil_self * (a.gamma_self[l] * p / 1.0 * pow(tr, ns));
+      const double ds = a.delta_self ? a.delta_self[l] : 0.0;
+      Shift0 += a.dil_self * ((ds + 0.0 * (T - H_TREF)) * p / 1.0);
+    }
+    // OmegaWingF and the window, misc/hapi.py:11131-11134
+    const double W = fmax(a.omega_wing, fmax(a.omega_wing_hw * Gamma0, a.omega_wing_hw * GammaD));
+    long long glo = grid_bisect_right(g, nu - W);
+    long long ghi = grid_bisect_right(g, nu + W);
+    int lo = clamp_local(glo, g), hi = clamp_local(ghi, g);
+    const bool dropped = !(w != 0.0) || (S < a.thresh) || !(GammaD > 0.0);
+    if (dropped || hi <= lo) { lo = 0; hi = 0; }
+    // profile parameters: pcqsdhc PART1, misc/hapi.py:9900-9915
+    const double sg0 = nu + Shift0;
+    const double cte = sqrt(log(2.0)) / GammaD;
+    const double y = Gamma0 * cte;
+    const double A = dropped ? 0.0 : w * S * cte / sqrt(M_PI) * a.scale;
+    // nearest grid index to the shifted centre (global), then the residual in fp64
+    long long gi0 = llrint((sg0 - g.xmin) / g.step);
+    const long long M = 1000000000LL;
+    if (gi0 < -M) gi0 = -M;
+    if (gi0 > M) gi0 = M;
+    const double frac_x = (grid_x(g, gi0) - sg0) * cte;  // x at gi0, |.| <= a/2 when inside the grid
+    const double ax = g.step * cte;
+    LineRec r;
+    r.a = (float)ax;
+    r.c = (float)frac_x;
+    r.y = (float)y;
+    r.A = (float)A;
+    r.i0 = sat_i32(gi0 - g.offset);
+    r.lo = lo;
+    r.hi = hi;
+    // half-width (grid points) of the band that can satisfy |x|+y<15 (hum1_wei switch, misc/hapi.py:9840)
+    int zw = 0;
+    if (y < 15.0 && hi > lo) {
+      double z = ceil((15.0 - y) / ax) + 2.0;
+      zw = z > 1.0e9 ? 1000000000 : (int)z;
+    }
+    r.zw = zw;
+    LineRec64 r64;
+    r64.sg0 = sg0; r64.cte = cte; r64.y = y; r64.A = A;
+    const size_t o = (size_t)k * (size_t)a.n_lines + (size_t)l;
+    a.rec[o] = r;
+    a.rec64[o] = r64;
+    if (k == 0) {
+      long long gic = llrint((nu - g.xmin) / g.step);
+      if (gic < -M) gic = -M;
+      if (gic > M) gic = M;
+      a.ic[l] = sat_i32(gic - g.offset);
+    }
+    if (hi > lo) {
+      // window half-width in grid points, measured from the unshifted centre, with margin
+      double hw = ceil(W / g.step) + 2.0;
+      my_hw = hw > 1.0e9 ? 1000000000 : (int)hw;
+    }
+  }
+  // block max -> one atomic per block
+  for (int off = 32; off > 0; off >>= 1) my_hw = max(my_hw, __shfl_down(my_hw, off));
+  __shared__ int s_hw[4];
+  if ((threadIdx.x & 63) == 0) s_hw[threadIdx.x >> 6] = my_hw;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int v = max(max(s_hw[0], s_hw[1]), max(s_hw[2], s_hw[3]));
+    if (v > 0) atomicMax(&a.maxhw[k], v);
+  }
+}
+
+extern "C" int rtx_line_prep(rtx_prep* P, const rtx_lines* L, const rtx_grid* grid, int n_layers, const double* T_h,
+                             const double* p_atm_h, const double* qratio_h, const double* weight_h, const double* mass_h,
+                             double dil_air, double dil_self, double omega_wing, double omega_wing_hw,
+                             double intensity_threshold, double scale, void* stream) {
+  if (!P || !L) RTX_FAIL("prep/lines is NULL");
+  if (rtx_check_grid(grid)) return 1;
+  if (P->n_lines != L->n) RTX_FAIL("prep object was created for %lld lines, table has %lld", P->n_lines, L->n);
+  if (n_layers < 1 || n_layers > P->max_layers) RTX_FAIL("n_layers=%d outside [1,%d]", n_layers, P->max_layers);
+  if (!T_h || !p_atm_h || !qratio_h || !weight_h || !mass_h) RTX_FAIL("a per-layer input is NULL");
+  if (!(scale > 0.0)) RTX_FAIL("scale must be > 0");
+  for (int k = 0; k < n_layers; ++k)
+    if (!(T_h[k] > 0.0) || !(p_atm_h[k] >= 0.0)) RTX_FAIL("layer %d: T=%g p=%g not physical", k, T_h[k], p_atm_h[k]);
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = L->n_species;
+  const size_t nT = (size_t)n_layers, nQ = (size_t)ns * n_layers;
+  if (2 * nT + 2 * nQ + ns > P->env_cap) RTX_FAIL("environment tables exceed prep capacity");
+  double* d = P->env;
+  // pageable-source async copies are staged by the runtime before returning: caller may reuse its arrays
+  RTX_HIP(hipMemcpyAsync(d, T_h, nT * sizeof(double), hipMemcpyHostToDevice, st));
+  RTX_HIP(hipMemcpyAsync(d + nT, p_atm_h, nT * sizeof(double), hipMemcpyHostToDevice, st));
+  RTX_HIP(hipMemcpyAsync(d + 2 * nT, qratio_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
+  RTX_HIP(hipMemcpyAsync(d + 2 * nT + nQ, weight_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
+  RTX_HIP(hipMemcpyAsync(d + 2 * nT + 2 * nQ, mass_h, ns * sizeof(double), hipMemcpyHostToDevice, st));
+  RTX_HIP(hipMemsetAsync(P->maxhw, 0, sizeof(int) * (size_t)n_layers, st));
+  P->n_layers = n_layers;
+  P->scale = scale;
+  if (L->n == 0) return 0;
+  PrepArgs a;
+  a.nu = L->nu; a.sw = L->sw; a.elower = L->elower; a.gamma_air = L->gamma_air; a.gamma_self = L->gamma_self;
+  a.n_air = L->n_air; a.n_self = L->n_self; a.delta_air = L->delta_air; a.deltap_air = L->deltap_air;
+  a.delta_self = L->delta_self; a.species = L->species;
+  a.n_lines = L->n; a.n_layers = n_layers; a.n_species = ns;
+  a.T = d; a.p = d + nT; a.qratio = d + 2 * nT; a.weight = d + 2 * nT + nQ; a.mass = d + 2 * nT + 2 * nQ;
+  a.dil_air = dil_air; a.dil_self = dil_self; a.omega_wing = omega_wing; a.omega_wing_hw = omega_wing_hw;
+  a.thresh = intensity_threshold; a.scale = scale;
+  a.g = to_dev(grid);
+  a.rec = P->rec; a.rec64 = P->rec64; a.ic = P->ic; a.maxhw = P->maxhw;
+  dim3 grd((unsigned)((L->n + 255) / 256), (unsigned)n_layers);
+  hipLaunchKernelGGL(line_prep_kernel, grd, dim3(256), 0, st, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,238 @@
+// Planck emission + Schwarzschild up/down-welling integration.
+//
+// rtx_planck : planckian(), reference radiative_transfer.py:792-848, fp64 like the reference.
+// rtx_tud    : body of compute_TUD after the OD loop, radiative_transfer.py:340-392.
+//
+// TUD mapping (CDNA4): lane <-> wavenumber (coalesced dword loads of the layer-major OD), one point
+// per lane; the lane keeps its NL optical depths and NL Planck values in VGPRs (the layer loops are
+// fully unrolled so the arrays never touch scratch) and runs the nL-step recurrences for every
+// slant angle out of registers: OD is read from HBM exactly once, B is never materialised
+// (the reference builds an (nX,nL) fp64 temporary, :340). The binding resource is the
+// transcendental pipe: (1 + N_angle) exp per wavenumber-layer point (stage B).
+//
+// Precision: exp arguments of the Planck term reach c2*nu/T ~ 40, where an fp32 argument alone
+// costs 2.4e-6; the argument is formed in fp64, split into integer and fractional powers of two,
+// and only the fractional part goes through v_exp_f32. Layer transmittances exp(-OD/cos) are
+// fp32 (arguments matter only while OD < ~20).
+#include <math.h>
+#include <string.h>
+
+#include "rtx_common.h"
+
+#define RT_C1 1.19104295315e-16  // radiative_transfer.py:71
+#define RT_C2 1.43877736830e-02  // radiative_transfer.py:72
+#define LOG2E 1.4426950408889634
+
+// ---------------------------------------------------------------------------------------------------
+struct PlanckArgs {
+  GridDev g;
+  const double* X;
+  long long nx, nT;
+  const double* T;
+  int wavelength;
+  double* out;
+};
+
+__global__ __launch_bounds__(256) void planck_kernel(PlanckArgs a) {
+  const long long total = a.nx * a.nT;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / a.nT, j = e - i * a.nT;
+    double X = a.X ? a.X[i] : grid_x(a.g, a.g.offset + i);
+    const double T = a.T[j];
+    double L;
+    if (a.wavelength) {
+      X = X * 1e-6;  // um -> m  (:839-841)
+      L = RT_C1 / (pow(X, 5.0) * (exp(RT_C2 / (X * T)) - 1.0));
+      L *= 1e-4;
+    } else {
+      X = X * 100.0;  // 1/cm -> 1/m  (:843-845)
+      L = RT_C1 * (X * X * X) / (exp(RT_C2 * X / T) - 1.0);
+      L *= 1e4;
+    }
+    a.out[e] = L;
+  }
+}
+
+extern "C" int rtx_planck(const rtx_grid* grid, const double* X, int64_t nx, const double* T, int64_t nT, int wavelength,
+                          double* out, void* stream) {
+  if (!X) {
+    if (rtx_check_grid(grid)) return 1;
+    if (nx != grid->n) RTX_FAIL("nx=%lld != grid->n=%lld", (long long)nx, (long long)grid->n);
+  }
+  if (nx < 0 || nT < 0) RTX_FAIL("negative size");
+  if (nx == 0 || nT == 0) return 0;
+  if (!T || !out) RTX_FAIL("T/out is NULL");
+  PlanckArgs a;
+  if (grid) a.g = to_dev(grid); else { a.g.xmin = a.g.xmax = a.g.step = 0; a.g.n_total = a.g.offset = a.g.n = 0; }
+  a.X = X; a.nx = nx; a.nT = nT; a.T = T; a.wavelength = wavelength; a.out = out;
+  const long long total = nx * nT;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(planck_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define TUD_MAX_LAYERS 128
+#define TUD_MAX_ANGLES 128
+#define TUD_MAX_ALT 16
+#define TUD_MAX_MU 8
+
+struct TudArgs {
+  const float* OD;
+  long long ld, ld_out;
+  GridDev g;
+  int n_layers, n_alt, n_mu, n_down, n_ang, return_od;
+  float* tau;
+  float* Lu;
+  float* Ld;
+  float* Ld_ang;                       // optional [n_ang_real][ld_out] per-stream radiances (opts['save'])
+  int n_ang_real;
+  float inv_wsum;                      // 1/sum(cos*sin) (inf/NaN propagate like the reference's 0/0)
+  double c2l2e_over_T[TUD_MAX_LAYERS]; // 100*c2*log2(e)/T_k
+  float ang_c[TUD_MAX_ANGLES];         // -log2(e)/cos(theta)
+  float ang_w[TUD_MAX_ANGLES];         // cos(theta)*sin(theta)
+  float mu_c[TUD_MAX_MU];              // -log2(e)*mu
+  float mu[TUD_MAX_MU];
+  unsigned int mask[TUD_MAX_ALT][TUD_MAX_LAYERS / 32];
+  int count[TUD_MAX_ALT];
+};
+
+// B(nu,T) in uW/(cm^2 sr cm^-1):  c1*(100 nu)^3*1e4 / (exp(c2*100 nu/T) - 1)
+__device__ __forceinline__ float planck_f32(double c1x3, double x, double c2l2e_over_T) {
+  const double t = x * c2l2e_over_T;  // log2 of the exponential, fp64
+  if (t < 1.5) {                      // small arguments (far-IR / microwave): expm1 in fp64
+    return (float)(c1x3 / expm1(t * 0.6931471805599453));
+  }
+  const double n = rint(t);
+  const float f = (float)(t - n);     // |f| <= 1/2, exact difference
+  const float e = ldexpf(__builtin_amdgcn_exp2f(f), (int)n);  // inf above 2^128: B -> 0, as it should
+  return (float)c1x3 * __builtin_amdgcn_rcpf(e - 1.0f);
+}
+
+template <int NL>
+__global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.g.n) return;
+  float od[NL], B[NL];
+  const int nL = a.n_layers;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) od[k] = (k < nL) ? a.OD[(size_t)k * a.ld + i] : 0.f;
+  {
+    const double x = grid_x(a.g, a.g.offset + i);
+    const double x100 = x * 100.0;
+    const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) B[k] = (k < nL) ? planck_f32(c1x3, x, a.c2l2e_over_T[k]) : 0.f;
+  }
+  // ---- transmittance + upwelling, per sensor altitude and slant factor (:346-356) ----------
+  for (int ia = 0; ia < a.n_alt; ++ia) {
+    const int cnt = a.count[ia];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NL; ++k)
+      if ((a.mask[ia][k >> 5] >> (k & 31)) & 1u) s += od[k];
+    for (int im = 0; im < a.n_mu; ++im) {
+      const float c = a.mu_c[im];
+      float Lu = 0.f;
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        if (k < cnt) {
+          const float t = __builtin_amdgcn_exp2f(od[k] * c);
+          Lu = fmaf(t, Lu - B[k], B[k]);  // t*Lu + (1-t)*B
+        }
+      }
+      const size_t o = (size_t)(ia * a.n_mu + im) * (size_t)a.ld_out + (size_t)i;
+      a.tau[o] = a.return_od ? s * a.mu[im] : __builtin_amdgcn_exp2f(s * c);
+      a.Lu[o] = Lu;
+    }
+  }
+  // ---- downwelling: n_ang streams, two at a time for ILP (:368-372, 387-388) ---------------
+  const int nd = a.n_down;
+  float acc = 0.f;
+  for (int ii = 0; ii < a.n_ang; ii += 2) {
+    const float c0 = a.ang_c[ii], c1 = a.ang_c[ii + 1];
+    float L0 = 0.f, L1 = 0.f;
+#pragma unroll
+    for (int k = NL - 1; k >= 0; --k) {
+      if (k < nd) {
+        const float t0 = __builtin_amdgcn_exp2f(od[k] * c0);
+        const float t1 = __builtin_amdgcn_exp2f(od[k] * c1);
+        L0 = fmaf(t0, L0 - B[k], B[k]);
+        L1 = fmaf(t1, L1 - B[k], B[k]);
+      }
+    }
+    acc = fmaf(L0, a.ang_w[ii], acc);
+    acc = fmaf(L1, a.ang_w[ii + 1], acc);
+    if (a.Ld_ang) {
+      a.Ld_ang[(size_t)ii * a.ld_out + i] = L0;
+      if (ii + 1 < a.n_ang_real) a.Ld_ang[(size_t)(ii + 1) * a.ld_out + i] = L1;
+    }
+  }
+  a.Ld[i] = acc * a.inv_wsum;
+}
+
+template <int NL>
+static int launch_tud(const TudArgs& a, hipStream_t st) {
+  const long long blocks = (a.g.n + 255) / 256;
+  hipLaunchKernelGGL(tud_kernel<NL>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_layers, const double* T_h, int n_alt,
+                       const uint8_t* mask_h, int n_mu, const double* mu_h, int n_down, int n_angle, int return_od,
+                       float* tau, float* Lu, float* Ld, float* Ld_angles, int64_t ld_out, void* stream) {
+  if (rtx_check_grid(grid)) return 1;
+  if (!OD || !T_h || !mask_h || !mu_h || !tau || !Lu || !Ld) RTX_FAIL("a required pointer is NULL");
+  if (n_layers < 1 || n_layers > TUD_MAX_LAYERS) RTX_FAIL("n_layers=%d outside [1,%d]", n_layers, TUD_MAX_LAYERS);
+  if (n_alt < 1 || n_alt > TUD_MAX_ALT) RTX_FAIL("n_alt=%d outside [1,%d]", n_alt, TUD_MAX_ALT);
+  if (n_mu < 1 || n_mu > TUD_MAX_MU) RTX_FAIL("n_mu=%d outside [1,%d]", n_mu, TUD_MAX_MU);
+  if (n_angle < 1 || n_angle > TUD_MAX_ANGLES - 1) RTX_FAIL("n_angle=%d outside [1,%d]", n_angle, TUD_MAX_ANGLES - 1);
+  if (n_down < 0 || n_down > n_layers) RTX_FAIL("n_down=%d outside [0,%d]", n_down, n_layers);
+  if (ld < grid->n || ld_out < grid->n) RTX_FAIL("leading dimension smaller than the shard");
+  if (grid->n == 0) return 0;
+  TudArgs a;
+  memset(&a, 0, sizeof(a));
+  a.OD = OD; a.ld = ld; a.ld_out = ld_out; a.g = to_dev(grid);
+  a.n_layers = n_layers; a.n_alt = n_alt; a.n_mu = n_mu; a.n_down = n_down; a.return_od = return_od;
+  a.tau = tau; a.Lu = Lu; a.Ld = Ld; a.Ld_ang = Ld_angles;
+  for (int k = 0; k < n_layers; ++k) {
+    if (!(T_h[k] > 0.0)) RTX_FAIL("layer %d temperature %g", k, T_h[k]);
+    a.c2l2e_over_T[k] = 100.0 * RT_C2 * LOG2E / T_h[k];
+  }
+  for (int ia = 0; ia < n_alt; ++ia) {
+    int c = 0;
+    for (int k = 0; k < n_layers; ++k)
+      if (mask_h[(size_t)ia * n_layers + k]) { a.mask[ia][k >> 5] |= 1u << (k & 31); ++c; }
+    a.count[ia] = c;
+  }
+  for (int m = 0; m < n_mu; ++m) { a.mu[m] = (float)mu_h[m]; a.mu_c[m] = (float)(-LOG2E * mu_h[m]); }
+  // angles = linspace(0, pi/2, nA, endpoint=False) (:368); weights cos*sin (:387). theta=0 has
+  // weight exactly 0 (sin 0 = 0) and is skipped; an odd count is padded with a weight-0 stream.
+  double wsum = 0.0;
+  int na = 0;
+  const double dth = (M_PI / 2.0) / (double)n_angle;  // np.linspace step
+  for (int ii = 0; ii < n_angle; ++ii) {
+    const double th = (double)ii * dth;
+    const double w = cos(th) * sin(th);
+    wsum += w;
+    if (ii == 0 && !Ld_angles) continue;  // with per-stream output every stream is evaluated
+    a.ang_c[na] = (float)(-LOG2E / cos(th));
+    a.ang_w[na] = (float)w;
+    ++na;
+  }
+  a.n_ang_real = na;
+  if (na & 1) { a.ang_c[na] = (float)(-LOG2E); a.ang_w[na] = 0.f; ++na; }
+  a.n_ang = na;
+  a.inv_wsum = (float)(1.0 / wsum);  // n_angle==1: 1/0 = inf, acc=0 -> NaN like the reference's 0/0
+  if (na == 0) a.inv_wsum = NAN;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_layers <= 16) return launch_tud<16>(a, st);
+  if (n_layers <= 32) return launch_tud<32>(a, st);
+  if (n_layers <= 48) return launch_tud<48>(a, st);
+  if (n_layers <= 64) return launch_tud<64>(a, st);
+  if (n_layers <= 96) return launch_tud<96>(a, st);
+  return launch_tud<128>(a, st);
+}

@@ -1,0 +1,298 @@
+"""Host-side engine: PyTorch-ROCm owns device memory and streams, libradtxfr_hip.so does the work.
+
+This is plumbing between the reference-shaped shims (radiative_transfer.py, hapi.py, ILS_MAKO.py in
+this package) and the C ABI (include/radtxfr_hip.h). Every compute call goes through the HIP
+library; nothing here falls back to NumPy or to the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, tips
+
+# hapi constants used for per-species / per-layer host factors (misc/hapi.py:84-92, 10163-10164)
+CBOLTS = 1.380648813e-16
+TREF = 296.0
+
+
+def volumeConcentration(p, T):
+    """Molecules/cm^3 at p [atm], T [K] (misc/hapi.py:10163-10164)."""
+    return (p / 9.869233e-7) / (CBOLTS * T)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.RtxError("no HIP device visible: radtxfr_amd has no CPU fallback (torch.cuda.is_available() is False)")
+
+
+def device(dev=None):
+    require_gpu()
+    if dev is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(dev)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _h(a):
+    """contiguous float64 host array + its pointer (kept alive by the caller holding the array)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class Grid:
+    """np.linspace(xmin, xmax, n_total) (radiative_transfer.py:269-270), optionally one shard of it."""
+
+    def __init__(self, xmin, xmax, n_total, offset=0, n=None):
+        self.c = _lib.make_grid(xmin, xmax, n_total, offset, n)
+
+    xmin = property(lambda s: s.c.xmin)
+    xmax = property(lambda s: s.c.xmax)
+    step = property(lambda s: s.c.step)
+    n_total = property(lambda s: s.c.n_total)
+    offset = property(lambda s: s.c.offset)
+    n = property(lambda s: s.c.n)
+
+    def shard(self, offset, n):
+        return Grid(self.xmin, self.xmax, self.n_total, offset, n)
+
+    def axis(self):
+        """Materialise this shard's wavenumbers (host fp64), bit-identical to np.linspace."""
+        X = np.linspace(self.xmin, self.xmax, self.n_total)
+        return X[self.offset:self.offset + self.n]
+
+    @staticmethod
+    def from_axis(X, rtol=1e-9):
+        """Recognise a uniform ascending axis; raises if X is not np.linspace-like."""
+        X = np.asarray(X, dtype=np.float64).ravel()
+        if X.size < 2:
+            raise ValueError("spectral axis needs at least 2 points")
+        g = Grid(X[0], X[-1], X.size)
+        dev = np.max(np.abs(X - np.linspace(X[0], X[-1], X.size)))
+        if not (g.step > 0) or dev > rtol * abs(g.step):
+            raise NotImplementedError("the HIP line-sum needs a uniform ascending wavenumber grid "
+                                      f"(max deviation from np.linspace = {dev:g}, step = {g.step:g})")
+        return g
+
+    def byref(self):
+        return C.byref(self.c)
+
+
+_COLS = ("nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air")
+_OPT_COLS = ("n_self", "deltap_air", "delta_self")
+
+
+class LineTable:
+    """Device-resident HITRAN-format line table, sorted by nu (include/radtxfr_hip.h: rtx_lines).
+    `columns` is the column dict of the reference's table type: LOCAL_TABLE_CACHE[name]['data']
+    (misc/hapi.py:438-463)."""
+
+    def __init__(self, columns):
+        require_gpu()
+        lib = _lib.load()
+        nu = np.asarray(columns["nu"], dtype=np.float64)
+        order = np.argsort(nu, kind="stable")
+        self.n = int(nu.size)
+        self.cols = {k: np.ascontiguousarray(np.asarray(columns[k], dtype=np.float64)[order]) for k in _COLS}
+        for k in _OPT_COLS:
+            if k in columns:
+                self.cols[k] = np.ascontiguousarray(np.asarray(columns[k], dtype=np.float64)[order])
+        M = np.asarray(columns["molec_id"]).astype(np.int64)[order]
+        I = np.asarray(columns["local_iso_id"]).astype(np.int64)[order]
+        self.molec_id, self.local_iso_id = M, I
+        pairs = sorted(set(zip(M.tolist(), I.tolist())))
+        self.species = pairs if pairs else [(0, 0)]
+        lut = {p: i for i, p in enumerate(self.species)}
+        sp = np.ascontiguousarray([lut[p] for p in zip(M.tolist(), I.tolist())], dtype=np.int32)
+        self._h = C.c_void_p(0)
+        ptr = lambda k: self.cols[k].ctypes.data_as(C.c_void_p) if k in self.cols else C.c_void_p(0)
+        _lib.check(lib.rtx_lines_create(
+            self.n, len(self.species), ptr("nu"), ptr("sw"), ptr("elower"), ptr("gamma_air"), ptr("gamma_self"),
+            ptr("n_air"), ptr("n_self"), ptr("delta_air"), ptr("deltap_air"), ptr("delta_self"),
+            sp.ctypes.data_as(C.c_void_p), C.byref(self._h)))
+        self._plans = {}
+
+    def plan(self, n_layers, n_points):
+        """A prep object big enough for (n_layers, n_points); cached, grown on demand."""
+        best = None
+        for (L, Np), p in self._plans.items():
+            if L >= n_layers and Np >= n_points:
+                best = p
+        if best is None:
+            best = VoigtPlan(self, n_layers, n_points)
+            self._plans = {k: v for k, v in self._plans.items() if not (k[0] <= n_layers and k[1] <= n_points)}
+            self._plans[(n_layers, n_points)] = best
+        return best
+
+    def close(self):
+        for p in self._plans.values():
+            p.close()
+        self._plans = {}
+        if self._h:
+            _lib.load().rtx_lines_free(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VoigtPlan:
+    """Per-(line, layer) record storage (rtx_prep)."""
+
+    def __init__(self, lines, max_layers, max_points):
+        self.lines = lines
+        self._h = C.c_void_p(0)
+        _lib.check(_lib.load().rtx_prep_create(lines._h, int(max_layers), int(max_points), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.load().rtx_prep_free(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def species_factors(species, T_layers, partitionFunction=None):
+    """qratio[nS][nL] = Q(Tref)/Q(T_k) (misc/hapi.py:11069-11070) and mass[nS] (:11086)."""
+    pf = partitionFunction or tips.PYTIPS
+    nS, nL = len(species), len(T_layers)
+    q = np.ones((nS, nL))
+    mass = np.ones(nS)
+    for s, (m, i) in enumerate(species):
+        if (m, i) == (0, 0):
+            continue
+        qref = pf(m, i, TREF)
+        mass[s] = tips.molecularMass(m, i)
+        for k, T in enumerate(T_layers):
+            q[s, k] = qref / pf(m, i, float(T))
+    return q, mass
+
+
+def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air=1.0, dil_self=0.0, omega_wing=0.0,
+              omega_wing_hw=50.0, intensity_threshold=0.0, scale=1.0, partitionFunction=None, qratio=None, mass=None):
+    """Prologue + line-sum for n_layers homogeneous states on `grid` (rtx_line_prep + rtx_voigt_sum).
+    weight[nS][nL] multiplies S(T) per species and layer. Outputs are [nL][grid.n] device tensors."""
+    lib = _lib.load()
+    T = np.atleast_1d(np.asarray(T, dtype=np.float64))
+    p_atm = np.atleast_1d(np.asarray(p_atm, dtype=np.float64))
+    nL = T.size
+    if qratio is None:
+        qratio, mass = species_factors(lines.species, T, partitionFunction)
+    plan = lines.plan(nL, grid.n)
+    T_h, T_p = _h(T)
+    p_h, p_p = _h(p_atm)
+    q_h, q_p = _h(qratio)
+    w_h, w_p = _h(np.broadcast_to(weight, (len(lines.species), nL)))
+    m_h, m_p = _h(mass)
+    st = _stream_ptr()
+    _lib.check(lib.rtx_line_prep(plan._h, lines._h, grid.byref(), nL, T_p, p_p, q_p, w_p, m_p, float(dil_air),
+                                 float(dil_self), float(omega_wing), float(omega_wing_hw), float(intensity_threshold),
+                                 float(scale), st))
+    ld = grid.n
+    for o, dt in ((out_f32, torch.float32), (out_f64, torch.float64)):
+        if o is not None:
+            assert o.dtype == dt and o.is_cuda and o.is_contiguous() and o.shape == (nL, ld), (o.dtype, o.shape)
+    _lib.check(lib.rtx_voigt_sum(plan._h, grid.byref(), nL, _ptr(out_f32), _ptr(out_f64), ld, st))
+    return out_f32, out_f64
+
+
+def layer_weights_od(species, T, P_pa, PL_km, MF_VAL, MF_ID):
+    """weight[nS][nL] for optical depth: n(p,T) * x_m * PL*1e5 for the line's molecule."""
+    T = np.asarray(T, dtype=np.float64)
+    p_atm = np.asarray(P_pa, dtype=np.float64) / 101325.0
+    PL = np.asarray(PL_km, dtype=np.float64)
+    MF_VAL = np.asarray(MF_VAL, dtype=np.float64).reshape(T.size, -1)
+    ids = [int(v) for v in np.asarray(MF_ID).ravel()]
+    w = np.zeros((len(species), T.size))
+    nvol = volumeConcentration(p_atm, T)
+    for s, (m, _) in enumerate(species):
+        if m in ids:
+            # `xs * (ppmv*1e-6) * PL * 1e5` with xs carrying factor = volumeConcentration (HITRAN_units=False)
+            w[s] = nvol * (MF_VAL[:, ids.index(m)] * 1e-6) * PL * 1e5
+    return w, p_atm
+
+
+def optical_depths(lines, grid, T, P_pa, PL_km, MF_VAL, MF_ID, out=None):
+    """OD[nL][grid.n] float32 on the device (layer-major, wavenumber-contiguous)."""
+    T = np.atleast_1d(np.asarray(T, dtype=np.float64))
+    w, p_atm = layer_weights_od(lines.species, T, np.atleast_1d(P_pa), np.atleast_1d(PL_km), MF_VAL, MF_ID)
+    if out is None:
+        out = torch.empty((T.size, grid.n), dtype=torch.float32, device=device())
+    voigt_sum(lines, grid, T, p_atm, w, out_f32=out)
+    return out
+
+
+def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=False, per_angle=False):
+    """tau[nAlt*nMu][n], Lu[nAlt*nMu][n], Ld[n] float32 device tensors from OD[nL][n] (rtx_tud)."""
+    lib = _lib.load()
+    T = np.atleast_1d(np.asarray(T, dtype=np.float64))
+    Z = np.atleast_1d(np.asarray(Z, dtype=np.float64))
+    Z_s = np.array([Altitudes], dtype=np.float64).ravel()
+    mu_s = np.array([1.0 / np.cos(theta_r)], dtype=np.float64).ravel()
+    nL = T.size
+    assert OD.dtype == torch.float32 and OD.is_cuda and OD.dim() == 2 and OD.shape[0] == nL and OD.shape[1] >= grid.n
+    assert OD.stride(1) == 1
+    mask = np.ascontiguousarray(np.stack([(Z <= zs) for zs in Z_s]).astype(np.uint8))
+    n_down = int(mask[-1].sum())  # quirk 3: nL is overwritten by the LAST altitude's count (:353, :370)
+    dev = OD.device
+    tau = torch.empty((Z_s.size * mu_s.size, grid.n), dtype=torch.float32, device=dev)
+    Lu = torch.empty_like(tau)
+    Ld = torch.empty((grid.n,), dtype=torch.float32, device=dev)
+    Ld_ang = torch.empty((int(N_angle), grid.n), dtype=torch.float32, device=dev) if per_angle else None
+    T_h, T_p = _h(T)
+    mu_h, mu_p = _h(mu_s)
+    _lib.check(lib.rtx_tud(_ptr(OD), OD.stride(0), grid.byref(), nL, T_p, Z_s.size, mask.ctypes.data_as(C.c_void_p),
+                           mu_s.size, mu_p, n_down, int(N_angle), int(bool(returnOD)), _ptr(tau), _ptr(Lu), _ptr(Ld),
+                           _ptr(Ld_ang), grid.n, _stream_ptr()))
+    if per_angle:
+        return tau, Lu, Ld, (Z_s.size, mu_s.size), Ld_ang
+    return tau, Lu, Ld, (Z_s.size, mu_s.size)
+
+
+def planck(X, T, wavelength=False, grid=None):
+    """out[nx][nT] float64 device tensor (rtx_planck). X: device fp64 tensor, or None with a Grid."""
+    lib = _lib.load()
+    nx = grid.n if X is None else X.numel()
+    out = torch.empty((nx, T.numel()), dtype=torch.float64, device=T.device)
+    _lib.check(lib.rtx_planck(grid.byref() if grid is not None else None, _ptr(X), nx, _ptr(T), T.numel(),
+                              int(bool(wavelength)), _ptr(out), _stream_ptr()))
+    return out
+
+
+def apparent_radiance(X, emis, Ts, tau, La, Ld, dT=None, return_Ls=False):
+    """Device tensors in, L[nX][nE][nA][nT or 1] float32 out (rtx_apparent_radiance)."""
+    lib = _lib.load()
+    nX, nE = emis.shape
+    nA = Ts.numel()
+    nT = dT.numel() if dT is not None else 1
+    L = torch.empty((nX, nE, nA, nT), dtype=torch.float32, device=emis.device)
+    Ls = torch.empty_like(L) if return_Ls else None
+    _lib.check(lib.rtx_apparent_radiance(_ptr(X), nX, _ptr(emis), nE, _ptr(Ts), nA, _ptr(tau), _ptr(La), _ptr(Ld),
+                                         _ptr(dT), nT if dT is not None else 0, _ptr(L), _ptr(Ls), _stream_ptr()))
+    return L, Ls
+
+
+def ils(kind, Y, centre, sigma, X=None, grid=None):
+    """Y[nx][nS] float32 device -> Y_out[nB][nS] float32 (rtx_ils). kind 0 triangle, 1 Gaussian."""
+    lib = _lib.load()
+    assert Y.dtype == torch.float32 and Y.is_cuda and Y.dim() == 2 and Y.stride(1) == 1
+    nx, nS = Y.shape
+    nB = centre.numel()
+    out = torch.empty((nB, nS), dtype=torch.float32, device=Y.device)
+    _lib.check(lib.rtx_ils(int(kind), grid.byref() if grid is not None else None, _ptr(X), nx, _ptr(Y), nS, Y.stride(0),
+                           nB, _ptr(centre), _ptr(sigma), _ptr(out), _stream_ptr()))
+    return out

@@ -1,0 +1,181 @@
+"""Drop-in for the hot-path part of the reference's vendored HITRAN API (misc/hapi.py).
+
+Only the functions on the north-star path are provided, with the reference's names, argument
+meaning and error behaviour:
+
+    absorptionCoefficient_Voigt   misc/hapi.py:10906-11141   -> HIP prologue + line-sum kernels
+    LOCAL_TABLE_CACHE             misc/hapi.py:438-463       (same dict layout)
+    PYTIPS / partitionSum pieces  misc/hapi.py:9568-9582, 10030
+    abundance, molecularMass      misc/hapi.py:5088-5124
+    volumeConcentration           misc/hapi.py:10163-10164
+
+The database client (fetch/select/...), the other line profiles and the slit functions are out of
+scope. There is no CPU fallback: without the HIP library and a
+GPU, absorptionCoefficient_Voigt raises.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import engine
+from .tips import PYTIPS, abundance, molecularMass, known_isotopologues  # noqa: F401  (re-exported API)
+
+volumeConcentration = engine.volumeConcentration
+
+DefaultIntensityThreshold = 0.0  # misc/hapi.py:10214
+DefaultOmegaWingHW = 50.0        # misc/hapi.py:10218
+
+# name -> {'header': {'number_of_rows': n, ...}, 'data': {column: list-or-array}}
+LOCAL_TABLE_CACHE = {}
+_DEVICE_TABLES = {}
+
+
+def storage2cache_from_columns(TableName, columns):
+    """Convenience: register a column dict as a table (what db_begin()/fetch() leave in the cache)."""
+    n = len(columns["nu"])
+    LOCAL_TABLE_CACHE[TableName] = {"header": {"number_of_rows": n, "table_name": TableName},
+                                    "data": {k: (v.tolist() if hasattr(v, "tolist") else list(v)) for k, v in columns.items()}}
+
+
+def _device_table(names):
+    """Device LineTable for one or several cached tables (concatenated); rebuilt if the data changed."""
+    key = tuple(names)
+    sig = tuple((id(LOCAL_TABLE_CACHE[n]["data"].get("nu")), LOCAL_TABLE_CACHE[n]["header"]["number_of_rows"]) for n in names)
+    hit = _DEVICE_TABLES.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    cols = {}
+    keys = None
+    for n in names:
+        d = LOCAL_TABLE_CACHE[n]["data"]
+        nrow = LOCAL_TABLE_CACHE[n]["header"]["number_of_rows"]
+        keys = set(d.keys()) if keys is None else keys & set(d.keys())
+        for k, v in d.items():
+            cols.setdefault(k, []).append(np.asarray(v)[:nrow])
+    use = [k for k in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air",
+                       "n_self", "deltap_air", "delta_self") if k in keys]
+    for req in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "n_air", "delta_air"):
+        if req not in use:
+            raise Exception("table(s) %s lack the column %s" % (names, req))
+    merged = {k: np.concatenate(cols[k]) for k in use}
+    if "gamma_self" not in merged:
+        merged["gamma_self"] = np.zeros(merged["nu"].size)  # hapi: missing gamma_<species> -> 0 (:11097-11100)
+    if hit is not None:
+        hit[1].close()
+    tbl = engine.LineTable(merged)
+    _DEVICE_TABLES[key] = (sig, tbl)
+    return tbl
+
+
+def listOfTuples(a):
+    """misc/hapi.py:10221-10228."""
+    if type(a) not in set([list, tuple]):
+        a = [a]
+    return a
+
+
+def arange_(lower, upper, step):
+    """misc/hapi.py:133-139 with the float-`num` crash fixed (npnt cast to int)."""
+    npnt = math.floor((upper - lower) / step) + 1
+    upper_new = lower + step * (npnt - 1)
+    if abs((upper - upper_new) - step) < 1e-10:
+        upper_new += step
+        npnt += 1
+    return np.linspace(lower, upper_new, int(npnt))
+
+
+def absorptionCoefficient_Voigt(Components=None, SourceTables=None, partitionFunction=PYTIPS, Environment=None,
+                                OmegaRange=None, OmegaStep=None, OmegaWing=None,
+                                IntensityThreshold=DefaultIntensityThreshold, OmegaWingHW=DefaultOmegaWingHW,
+                                GammaL="gamma_air", HITRAN_units=True, LineShift=True, File=None, Format=None,
+                                OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
+                                WavenumberWingHW=None, WavenumberGrid=None, Diluent={}, EnvDependences=None):
+    """Absorption coefficient with the Voigt profile; same inputs/outputs as misc/hapi.py:10906-11141.
+
+    Returns (Omegas, Xsect) as float64 NumPy arrays. The sum over lines runs on the GPU
+    (rtx_line_prep + rtx_voigt_sum); line strengths are carried in fp32 with a power-of-two scale,
+    so Xsect agrees with the reference to ~1e-6 relative, not bit for bit.
+    Not supported (raises): EnvDependences hooks, diluents other than air/self, non-uniform grids.
+    """
+    if WavenumberRange is not None: OmegaRange = WavenumberRange
+    if WavenumberStep: OmegaStep = WavenumberStep
+    if WavenumberWing: OmegaWing = WavenumberWing
+    if WavenumberWingHW: OmegaWingHW = WavenumberWingHW
+    if WavenumberGrid is not None: OmegaGrid = WavenumberGrid
+    if EnvDependences:
+        raise NotImplementedError("EnvDependences hooks are not supported by the HIP line-sum")
+    Components = listOfTuples(Components)
+    SourceTables = listOfTuples(SourceTables)
+    # getDefaultValuesForXsect, misc/hapi.py:10231-10281
+    if SourceTables[0] is None:
+        SourceTables = ["__BUFFER__"]
+    for TableName in SourceTables:
+        if TableName not in LOCAL_TABLE_CACHE:
+            raise Exception("%s: no such table. Check tableList() for more info." % TableName)
+    if Environment is None:
+        Environment = {"T": 296.0, "p": 1.0}
+    tbl = _device_table(SourceTables)
+    if Components == [None]:
+        Components = [p for p in tbl.species if p != (0, 0)]
+    if OmegaRange is None:
+        nu = tbl.cols["nu"]
+        OmegaRange = (float(nu.min()), float(nu.max())) if nu.size else (0.0, 0.0)
+    if OmegaStep is None:
+        OmegaStep = 0.01
+    if OmegaWing is None:
+        OmegaWing = 0.0
+    if not Format:
+        Format = "%.12f %e"
+    if OmegaStep > 0.1:
+        print("WARNING: Big wavenumber step: possible accuracy decline")
+    if OmegaGrid is not None:
+        Omegas = np.sort(np.asarray(OmegaGrid, dtype=np.float64))
+    else:
+        Omegas = arange_(OmegaRange[0], OmegaRange[1], OmegaStep)
+    T = Environment["T"]
+    p = Environment["p"]
+    # abundances, misc/hapi.py:10996-11009
+    ABUNDANCES, NATURAL = {}, {}
+    for Component in Components:
+        M, I = int(Component[0]), int(Component[1])
+        nat = abundance(M, I)
+        ABUNDANCES[(M, I)] = Component[2] if len(Component) >= 3 else nat
+        NATURAL[(M, I)] = nat
+    factor = 1.0 if HITRAN_units else volumeConcentration(p, T)
+    GammaL = GammaL.lower()
+    if not Diluent:
+        if GammaL == "gamma_air":
+            Diluent = {"air": 1.0}
+        elif GammaL == "gamma_self":
+            Diluent = {"self": 1.0}
+        else:
+            raise Exception("Unknown GammaL value: %s" % GammaL)
+    dil = {k.lower(): float(v) for k, v in Diluent.items()}
+    extra = set(dil) - {"air", "self"}
+    if extra:
+        raise NotImplementedError("diluents %s are not supported (air, self only)" % sorted(extra))
+    if Omegas.size < 2:
+        raise NotImplementedError("the HIP line-sum needs a grid of at least 2 points")
+    grid = engine.Grid.from_axis(Omegas)
+    # per-species weight = factor / natural * abundance (misc/hapi.py:11136-11137); 0 filters the species out (:11066)
+    w = np.zeros((len(tbl.species), 1))
+    for s, mi in enumerate(tbl.species):
+        if mi in ABUNDANCES:
+            w[s, 0] = factor / NATURAL[mi] * ABUNDANCES[mi]
+    # fold a power of two into the fp32 strengths so HITRAN-unit intensities (~1e-19..1e-30) stay normal
+    smax = float(np.max(tbl.cols["sw"])) * float(np.max(w)) if tbl.n and np.max(w) > 0 else 1.0
+    scale = 2.0 ** (-math.floor(math.log2(smax))) if smax > 0 and math.isfinite(smax) else 1.0
+    if tbl.n == 0:
+        Xsect = np.zeros(Omegas.size)
+    else:
+        out = torch.empty((1, grid.n), dtype=torch.float64, device=engine.device())
+        engine.voigt_sum(tbl, grid, [T], [p], w, out_f64=out, dil_air=dil.get("air", 0.0), dil_self=dil.get("self", 0.0),
+                         omega_wing=OmegaWing, omega_wing_hw=OmegaWingHW, intensity_threshold=IntensityThreshold,
+                         scale=scale, partitionFunction=partitionFunction)
+        Xsect = out[0].cpu().numpy()
+    if File:
+        with open(File, "w") as f:
+            for o, x in zip(Omegas, Xsect):
+                f.write((Format % (o, x)) + "\n")
+    return Omegas, Xsect

@@ -1,0 +1,259 @@
+"""Drop-in for the hot-path functions of the reference's radiative_transfer.py.
+
+Same names, positional order, keyword names and return shapes (spectral axis first) as the
+reference (radiative_transfer.py:22-25, signatures listed in SURVEY.md section 8b):
+
+    planckian                         :792-848
+    make_spectral_axis                :251-271
+    compute_OD                        :395-456    (LBLRTM replaced, see below)
+    compute_TUD                       :274-392
+    compute_LWIR_apparent_radiance    :1017-1069
+    ILS_MAKO                          :1072-1263
+    options, StdAtmos                 :75-183
+
+NumPy in -> NumPy out (float64, like the reference); torch CUDA tensors in -> torch out where the
+function is elementwise. All arithmetic runs in libradtxfr_hip.so on the GPU; there is no CPU path.
+
+Conscious divergences from the reference:
+  * compute_OD: the reference shells out to the LBLRTM Fortran binary with the AER line file; both
+    are git-LFS stubs. Here OD(nu) = sum_m k_m(nu; T, p) x_m PL from the Voigt line-sum over the line
+    table named by opts["line_table"] (a table in radtxfr_amd.hapi.LOCAL_TABLE_CACHE, or a column
+    dict). No continuum. Chunking / TAPE5 / TAPE12 plumbing does not exist.
+  * options are copied per call: kwargs no longer leak into the module-level default (quirk 2).
+  * make_spectral_axis casts the point count to int (quirk 1: the reference crashes on NumPy>=1.18).
+  * spectra are computed in float32 on the device and returned as float64.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import engine
+from . import hapi as _hapi
+
+# Module constants (radiative_transfer.py:71-72)
+c1 = 1.19104295315e-16  # [J m^2 / s]
+c2 = 1.43877736830e-02  # [m K]
+
+# 66-layer 1976 US standard atmosphere. The reference embeds a rounded copy (:77-144) of its
+# StandardAtmosphere.csv (2 decimals for Z/PL/P/T, %.3E for the mixing ratios); this package ships
+# the CSV (input fixture) and applies the same rounding, which reproduces the embedded table exactly
+# (tests/test_host.py checks it against a fixture captured from the reference).
+_CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "StandardAtmosphere.csv")
+StdAtmosCSV = np.loadtxt(_CSV, delimiter=",", skiprows=1)
+StdAtmos = StdAtmosCSV.copy()
+StdAtmos[:, 1:6] = np.round(StdAtmosCSV[:, 1:6], 2)
+StdAtmos[:, 6:] = np.vectorize(lambda v: float("%.3E" % v))(StdAtmosCSV[:, 6:])
+
+options = {
+    "DVOUT": 0.0005,  # [cm^{-1}]
+    "T": 296.0, "P": 101325.0, "PL": 1.0,
+    "MF_ID": np.array([]), "MF_VAL": np.array([]),
+    "line_table": None,  # replaces "LBLRTM"/"TAPE3": name in hapi.LOCAL_TABLE_CACHE or column dict
+    # options for compute_TUD (:172-182)
+    "Zs": StdAtmos[:, 1], "Ts": StdAtmos[:, 5], "Ps": StdAtmos[:, 4], "PLs": StdAtmos[:, 3],
+    "MFs_VAL": StdAtmos[:, 6:14] * 1e6, "MFs_ID": np.array([1, 2, 3, 4, 5, 6, 7, 22]),
+    "theta_r": 0, "N_angle": 30, "Altitudes": np.asarray([500]), "save": False, "returnOD": False,
+}
+
+
+def _is_torch(x):
+    return isinstance(x, torch.Tensor)
+
+
+def _dev_f64(x, dev):
+    if _is_torch(x):
+        return x.to(device=dev, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=dev)
+
+
+def _dev_f32(x, dev):
+    if _is_torch(x):
+        return x.to(device=dev, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=dev)
+
+
+def make_spectral_axis(Xmin, Xmax, DVOUT):
+    """:251-271. Spacing is (Xmax-Xmin)/(nX-1), not DVOUT, exactly like the reference."""
+    nX = int(np.ceil((Xmax - Xmin) / DVOUT))
+    return np.linspace(Xmin, Xmax, nX)
+
+
+def planckian(X_in, T_in, wavelength=False):
+    """Planck spectral radiance, :792-848. Output shape (X.size, *T.shape);
+    [uW/(cm^2 sr cm^-1)] or, for wavelength input in um, [uW/(cm^2 sr um)]."""
+    as_torch = _is_torch(X_in) or _is_torch(T_in)
+    dev = engine.device()
+    X = _dev_f64(X_in, dev).flatten()
+    T = _dev_f64(T_in, dev)
+    dimsT = tuple(T.shape)
+    if wavelength or float(X.mean()) < 50:
+        if not wavelength:
+            print("Assumes X given in µm; returning L in µF")
+        wavelength = True
+    L = engine.planck(X, T.flatten(), wavelength=wavelength).reshape((X.numel(), *dimsT))
+    return L if as_torch else L.cpu().numpy()
+
+
+def _resolve_table(spec):
+    if spec is None:
+        raise Exception("compute_OD: set opts['line_table'] to a table in radtxfr_amd.hapi.LOCAL_TABLE_CACHE "
+                        "(the reference's LBLRTM binary and AER TAPE3 are git-LFS stubs; there is no built-in line file)")
+    if isinstance(spec, engine.LineTable):
+        return spec
+    if isinstance(spec, str):
+        if spec not in _hapi.LOCAL_TABLE_CACHE:
+            raise Exception("%s: no such table. Check tableList() for more info." % spec)
+        return _hapi._device_table([spec])
+    if isinstance(spec, dict):
+        key = "__dict_%d" % id(spec)
+        if key not in _hapi.LOCAL_TABLE_CACHE or _hapi.LOCAL_TABLE_CACHE[key].get("_src") is not spec:
+            _hapi.LOCAL_TABLE_CACHE[key] = {"header": {"number_of_rows": len(spec["nu"])}, "data": spec, "_src": spec}
+        return _hapi._device_table([key])
+    raise TypeError("opts['line_table'] must be a table name, a column dict or an engine.LineTable")
+
+
+def compute_OD(Xmin_in, Xmax_in, opts=options, **kwargs):
+    """Monochromatic optical depth of one homogeneous layer, signature of :395-456.
+    kwargs honoured: T [K], P [Pa], PL [km], MF_VAL [ppmv], MF_ID (HITRAN ids), DVOUT, line_table.
+    Returns (X_out, OD_out)."""
+    o = dict(opts)
+    o.update(kwargs)
+    DVOUT = o.get("DVOUT", 0.025)
+    X = make_spectral_axis(Xmin_in, Xmax_in, DVOUT)
+    tbl = _resolve_table(o.get("line_table"))
+    grid = engine.Grid(Xmin_in, Xmax_in, X.size)
+    OD = engine.optical_depths(tbl, grid, [o["T"]], [o["P"]], [o["PL"]], np.asarray(o["MF_VAL"], dtype=np.float64)[None, :],
+                               o["MF_ID"])
+    return X, OD[0].double().cpu().numpy()
+
+
+def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
+    """Monochromatic transmittance, upwelling and downwelling radiance, signature of :274-392.
+
+    kwargs honoured (:304-314): DVOUT, Zs, Ts, Ps, PLs, MFs_VAL, MFs_ID, theta_r, N_angle, Altitudes,
+    save, returnOD, plus line_table. Returns (X, tau, Lu, Ld); tau/Lu are (nX,), (nX,nMu), (nX,nZ) or
+    (nX,nZ,nMu) by the reference's squeeze rules (:357-365); Ld is (nX,).
+    Quirks 3-6 of SURVEY.md section 9 are reproduced (downwelling uses the layer count of the last
+    sensor altitude; tau uses the Z<=zs mask, L-up the first count layers; returnOD; theta=0 weight 0).
+    """
+    o = dict(opts)
+    o.update(kwargs)
+    Z = np.asarray(o["Zs"], dtype=np.float64)
+    T = np.asarray(o["Ts"], dtype=np.float64)
+    P = np.asarray(o["Ps"], dtype=np.float64)
+    PL = np.asarray(o["PLs"], dtype=np.float64)
+    MF = np.asarray(o["MFs_VAL"], dtype=np.float64)
+    ID = np.asarray(o["MFs_ID"])
+    nA = int(o["N_angle"])
+    f = lambda x: np.array([x]).ravel()
+    Z_s = f(o["Altitudes"])
+    mu_s = f(1.0 / np.cos(o["theta_r"]))
+    if mu_s.size != 1:
+        raise NotImplementedError("theta_r must be a scalar (one slant path per call)")
+    X_ = make_spectral_axis(Xmin, Xmax, o["DVOUT"])
+    grid = engine.Grid(Xmin, Xmax, X_.size)
+    tbl = _resolve_table(o.get("line_table"))
+    OD = engine.optical_depths(tbl, grid, T, P, PL, MF, ID)  # [nL][nX] float32 on the device
+    res = engine.tud(OD, grid, T, Z, Altitudes=Z_s, theta_r=float(np.asarray(o["theta_r"]).ravel()[0]), N_angle=nA,
+                     returnOD=bool(o["returnOD"]), per_angle=bool(o["save"]))
+    tau, Lu, Ld, (nZ, nMu) = res[:4]
+    tau_ = tau.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1)
+    Lu_ = Lu.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1)
+    Ld_ = Ld.double().cpu().numpy()
+    if o["save"]:
+        angles = np.linspace(0, np.pi / 2.0, nA, endpoint=False)
+        np.savez("ComputeTUD.npz", OD=OD.double().cpu().numpy().T, B=planckian(X_, T), tau=tau_, Ld=res[4].double().cpu().numpy().T,
+                 Lu=Lu_, X=X_, angles=angles, Z_s=Z_s, mu_s=mu_s)
+    if (len(Z_s) == 1) and (len(mu_s) == 1):
+        tau_, Lu_ = tau_[:, 0, 0], Lu_[:, 0, 0]
+    elif len(Z_s) == 1:
+        tau_, Lu_ = tau_[:, 0, :], Lu_[:, 0, :]
+    elif len(mu_s) == 1:
+        tau_, Lu_ = tau_[:, :, 0], Lu_[:, :, 0]
+    return X_, np.ascontiguousarray(tau_), np.ascontiguousarray(Lu_), Ld_
+
+
+def compute_LWIR_apparent_radiance(X, emis, Ts, tau, La, Ld, dT=None, return_Ls=False):
+    r"""L = tau [emis B(Ts + dT) + (1 - emis) Ld] + La for every combination, signature of :1017-1069.
+
+    X (nX,), emis (nX,nE), Ts (nA,), tau/La/Ld (nX,nA), dT (nT,) optional ->
+    L (nX,nE,nA) or (nX,nE,nA,nT) [, Ls]. Computed in float32 (the reference's own caller casts its
+    inputs to float32 first, Compute_LWIR_Apparent_Radiance.py:9-20); NumPy in -> same dtype as `emis` out.
+    """
+    as_torch = any(_is_torch(v) for v in (X, emis, Ts, tau, La, Ld))
+    dev = engine.device()
+    Xd = _dev_f64(X, dev).flatten()
+    em = _dev_f32(emis, dev)
+    Tsd = _dev_f64(Ts, dev).flatten()
+    nX, nA = Xd.numel(), Tsd.numel()
+    td, Lad, Ldd = (_dev_f32(v, dev).reshape(nX, nA) for v in (tau, La, Ld))
+    dTd = _dev_f64(np.asarray(dT).flatten() if not _is_torch(dT) else dT.flatten(), dev) if dT is not None else None
+    L, Ls = engine.apparent_radiance(Xd, em.reshape(nX, -1), Tsd, td, Lad, Ldd, dTd, return_Ls)
+    if dT is None:
+        L = L[..., 0]
+        Ls = Ls[..., 0] if Ls is not None else None
+    if not as_torch:
+        odt = np.asarray(emis).dtype if np.asarray(emis).dtype in (np.float32, np.float64) else np.float64
+        L = L.cpu().numpy().astype(odt, copy=False)
+        Ls = Ls.cpu().numpy().astype(odt, copy=False) if Ls is not None else None
+    return (L, Ls) if return_Ls else L
+
+
+# 128 MAKO band centres [um] -- instrument constants listed at :1092-1223
+_MAKO_UM = np.array([
+    7.5711, 7.6158, 7.6606, 7.7053, 7.7500, 7.7947, 7.8394, 7.8841, 7.9288, 7.9734, 8.0181, 8.0627,
+    8.1073, 8.1519, 8.1965, 8.2411, 8.2857, 8.3303, 8.3748, 8.4194, 8.4639, 8.5084, 8.5529, 8.5974,
+    8.6419, 8.6863, 8.7308, 8.7752, 8.8197, 8.8641, 8.9085, 8.9529, 8.9973, 9.0417, 9.0860, 9.1304,
+    9.1747, 9.2190, 9.2633, 9.3076, 9.3519, 9.3962, 9.4405, 9.4847, 9.5290, 9.5732, 9.6174, 9.6616,
+    9.7058, 9.7500, 9.7942, 9.8383, 9.8825, 9.9266, 9.9707, 10.0148, 10.0589, 10.1030, 10.1471,
+    10.1912, 10.2352, 10.2792, 10.3233, 10.3673, 10.4113, 10.4553, 10.4993, 10.5432, 10.5872,
+    10.6311, 10.6751, 10.7190, 10.7629, 10.8068, 10.8507, 10.8945, 10.9384, 10.9822, 11.0261,
+    11.0699, 11.1137, 11.1575, 11.2013, 11.2451, 11.2888, 11.3326, 11.3763, 11.4201, 11.4638,
+    11.5075, 11.5512, 11.5948, 11.6385, 11.6822, 11.7258, 11.7694, 11.8131, 11.8567, 11.9003,
+    11.9439, 11.9874, 12.0310, 12.0745, 12.1181, 12.1616, 12.2051, 12.2486, 12.2921, 12.3356,
+    12.3791, 12.4225, 12.4660, 12.5094, 12.5528, 12.5962, 12.6396, 12.6830, 12.7264, 12.7697,
+    12.8131, 12.8564, 12.8997, 12.9430, 12.9863, 13.0296, 13.0729, 13.1162, 13.1594])
+
+
+def _ils_apply(kind, X, Y, centre, sigma):
+    """Shared device path of both ILS variants: Y (nX,) or (nX,nS) -> (nB,) or (nB,nS)."""
+    as_torch = _is_torch(Y)
+    dev = engine.device()
+    Yd = _dev_f32(Y, dev)
+    one_d = Yd.dim() == 1
+    if one_d:
+        Yd = Yd[:, None].contiguous()
+    Xh = X.detach().cpu().numpy() if _is_torch(X) else np.asarray(X, dtype=np.float64)
+    try:
+        grid, Xd = engine.Grid.from_axis(Xh), None
+    except NotImplementedError:
+        grid, Xd = None, _dev_f64(Xh, dev)  # explicit (non-uniform) ascending axis
+    out = engine.ils(kind, Yd, _dev_f64(centre, dev), _dev_f64(sigma, dev), X=Xd, grid=grid)
+    if one_d:
+        out = out[:, 0]
+    if as_torch:
+        return out
+    odt = np.asarray(Y).dtype if np.asarray(Y).dtype in (np.float32, np.float64) else np.float64
+    return out.cpu().numpy().astype(odt)
+
+
+def ILS_MAKO(X, Y, resFactor=None, returnX=True, fwhm_sf=1.0, shift=0.0, scale=1.0):
+    """MAKO instrument line shape (triangle), signature of :1072-1263.
+
+    X (nX,) ascending wavenumbers, Y (nX,) or (nX,nS) -> X_out (nB,), Y_out (nB,) or (nB,nS);
+    nB = 128 (or int(128*resFactor)) minus the bands outside the open interval (X.min, X.max) (:1233).
+    A band whose triangle covers no grid point comes out NaN, as in the reference (quirk 13)."""
+    Xh = X.detach().cpu().numpy() if _is_torch(X) else np.asarray(X, dtype=np.float64)
+    X_out = _MAKO_UM.copy()
+    if resFactor is not None:
+        _x0 = np.linspace(0, 1, len(X_out))
+        _x1 = np.linspace(0, 1, int(len(X_out) * resFactor))
+        X_out = np.interp(_x1, _x0, X_out)
+    X_out = np.sort(10000.0 / X_out)
+    X_out = X_out[(X_out > Xh.min()) & (X_out < Xh.max())]
+    sigma_out = fwhm_sf * np.abs(np.gradient(X_out)) * 1.6
+    Y_out = _ils_apply(0, Xh, Y, scale * X_out + shift, sigma_out)
+    if returnX:
+        return X_out, Y_out
+    return Y_out

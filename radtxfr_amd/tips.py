@@ -1,0 +1,89 @@
+"""TIPS-2011 total internal partition sums and the isotopologue table (host side, fp64).
+
+Mirrors the small per-species part of the reference's hapi chain that stays on the host:
+PYTIPS / BD_TIPS_2011_PYTHON (misc/hapi.py:9568-9582, 10030) with its 3-/4-point Lagrange
+interpolation AtoB (:5311-5388) on the nodes Tdat = 60:25:3010 K (:5401-5413), and the
+ISO abundance / molar-mass table (:3372-3496, 5088-5124). The tables themselves are data
+(radtxfr_amd/data/tips2011.npz, produced by oracle/make_tables.py).
+
+Per call this is n_species * n_layers interpolations -- the per-LINE work (which the reference
+repeats for every line, misc/hapi.py:11069-11070) runs on the GPU in rtx_line_prep.
+"""
+import os
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tips2011.npz")
+_T = None
+
+
+def _tab():
+    global _T
+    if _T is None:
+        d = np.load(_DATA, allow_pickle=False)
+        _T = {
+            "tdat": d["tdat"].astype(np.float64),
+            "q": {tuple(k): d["q"][r].astype(np.float64) for r, k in enumerate(d["mi"].tolist())},
+            "abun": {tuple(k): float(v) for k, v in zip(d["iso_mi"].tolist(), d["iso_abun"])},
+            "mass": {tuple(k): float(v) for k, v in zip(d["iso_mi"].tolist(), d["iso_mass"])},
+        }
+    return _T
+
+
+def _lagrange(aa, A, B, idx):
+    """Lagrange polynomial through nodes idx (3 or 4 of them), evaluated factor by factor in the
+    same order as the reference so results agree to the last bits."""
+    bb = 0.0
+    for j in idx:
+        num = 1.0
+        den = 1.0
+        for m in idx:
+            if m != j:
+                num = num * (aa - A[m])
+                d = A[j] - A[m]
+                den = den * (d if d != 0.0 else 0.0001)
+        bb = bb + (num / den) * B[j]
+    return bb
+
+
+def partition_sum(M, I, T):
+    """Q(T) for isotopologue (M,I); raises outside 70..3000 K like the reference (:9571)."""
+    T = float(T)
+    if T < 70.0 or T > 3000.0:
+        raise Exception("TIPS: T must be between 70K and 3000K.")
+    t = _tab()
+    key = (int(M), int(I))
+    if key not in t["q"] or not np.isfinite(t["q"][key][0]):
+        raise Exception("TIPS: no data for M,I = %d,%d." % key)
+    A, B = t["tdat"], t["q"][key]
+    npt = A.size
+    # first 1-based I >= 2 with A[I-1] >= T  (:5320-5321)
+    I1 = int(np.searchsorted(A[1:], T, side="left")) + 2
+    if I1 < 3 or I1 == npt:
+        J = (3 if I1 < 3 else npt) - 1
+        return _lagrange(T, A, B, (J - 2, J - 1, J))
+    J = I1 - 1
+    return _lagrange(T, A, B, (J - 2, J - 1, J, J + 1))
+
+
+PYTIPS = partition_sum
+
+
+def abundance(M, I):
+    """Natural abundance, misc/hapi.py:5088-5103."""
+    try:
+        return _tab()["abun"][(int(M), int(I))]
+    except KeyError:
+        raise Exception("cannot find component M,I = %d,%d." % (M, I))
+
+
+def molecularMass(M, I):
+    """Molar mass [g/mol], misc/hapi.py:5109-5124."""
+    try:
+        return _tab()["mass"][(int(M), int(I))]
+    except KeyError:
+        raise Exception("cannot find component M,I = %d,%d." % (M, I))
+
+
+def known_isotopologues():
+    return sorted(_tab()["abun"].keys())

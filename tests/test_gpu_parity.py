@@ -1,0 +1,313 @@
+"""GPU parity tests proper: the HIP path (through the C ABI via the reference-shaped shims) against
+(a) the golden vectors captured from the imported reference and (b) the CPU oracle on seeded inputs.
+
+Tolerances (SURVEY.md 8d, fp64 reference -> fp32 engine):
+    radiances / cross sections / OD : max |x-ref| / max(|ref|, 1e-3 max|ref|) <= 1e-5
+    transmittance                   : |dtau| <= 2e-6 absolute
+    fp64 entry points (planckian)   : 1e-12 relative
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import cpu_ref as ref
+from radtxfr_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL_L = 1e-5
+TOL_TAU = 2e-6
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test without a GPU"
+    from radtxfr_amd import _lib
+    _lib.load()
+    from radtxfr_amd import radiative_transfer
+    return radiative_transfer
+
+
+@pytest.fixture(scope="module")
+def hapi(rt):
+    from radtxfr_amd import hapi as h
+    return h
+
+
+def test_native_library_loaded(rt):
+    import os
+    from radtxfr_amd import _lib
+    with open("/proc/self/maps") as f:
+        assert any(os.path.basename(_lib.LIB_PATH) in ln for ln in f), "libradtxfr_hip.so is not mapped"
+
+
+# ------------------------------------------------------------------------------------ G1 planckian
+def test_g1_planckian(rt, golden):
+    g = golden("g1_planck.npz")
+    L = rt.planckian(g["X"], g["T32"])
+    assert L.shape == g["L32"].shape and L.dtype == np.float64
+    np.testing.assert_allclose(L, g["L32"], rtol=1e-12)
+    Ls = rt.planckian(g["X"], 296.0)
+    assert Ls.shape == (g["X"].size,)
+    np.testing.assert_allclose(Ls, g["Ls"], rtol=1e-12)
+    np.testing.assert_allclose(rt.planckian(g["Xum"], g["T32"][:5], wavelength=True), g["Lum"], rtol=1e-12)
+    L2 = rt.planckian(g["X"], g["T2d"])
+    assert L2.shape == (g["X"].size, 2, 3)
+    np.testing.assert_allclose(L2, g["L2d"], rtol=1e-12)
+    np.testing.assert_allclose(rt.planckian(500.0, 296)[0], 1.436645756277321e+01, rtol=1e-12)
+    # wavelength heuristic mean(X) < 50 (:836)
+    np.testing.assert_allclose(rt.planckian(np.array([10.0]), 300.0)[0], 9.924016798845834e+02, rtol=1e-12)
+
+
+# --------------------------------------------------------------------- G4 absorptionCoefficient_Voigt
+def _g4_table(hapi, g):
+    tbl = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    hapi.storage2cache_from_columns("g4", tbl)
+    return np.linspace(float(g["grid_lo"]), float(g["grid_hi"]), int(g["grid_n"]))
+
+
+@pytest.mark.parametrize("tag", ["l01", "l32"])
+def test_g4_voigt_xsec_golden(hapi, golden, tag):
+    g = golden("g4_voigt_xsec.npz")
+    grid = _g4_table(hapi, g)
+    om, xs = hapi.absorptionCoefficient_Voigt(SourceTables="g4", Environment={"T": float(g["T_" + tag]), "p": float(g["p_" + tag])},
+                                              OmegaGrid=grid, HITRAN_units=True)
+    assert np.array_equal(om, grid) and xs.dtype == np.float64
+    assert rel_err(xs, g["xs_" + tag]) <= TOL_L
+
+
+def test_g4_voigt_options_golden(hapi, golden):
+    g = golden("g4_voigt_xsec.npz")
+    grid = _g4_table(hapi, g)
+    _, xs = hapi.absorptionCoefficient_Voigt(Components=[(1, 1), (2, 1, 0.5)], SourceTables="g4", Environment={"T": 250.0, "p": 0.4},
+                                             OmegaGrid=grid[20000:30000], HITRAN_units=False, GammaL="gamma_self",
+                                             OmegaWing=2.0, OmegaWingHW=20.0)
+    assert rel_err(xs, g["xs_opt"]) <= TOL_L
+    _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="g4", Environment={"T": 230.0, "p": 0.05}, OmegaGrid=grid[40000:46000],
+                                             Diluent={"air": 0.7, "self": 0.3})
+    assert rel_err(xs, g["xs_dil"]) <= TOL_L
+
+
+def test_voigt_window_edges_exact(hapi):
+    """The hard wing cutoff must land on the same grid points as bisect() (quirk 8): compare the
+    support (non-zero set) of single-line cross sections with the oracle's, point for point."""
+    tbl = synthetic.synth_line_table(99, 40, 995.0, 1005.0)
+    grid = np.linspace(990.0, 1010.0, 20000)
+    for r in range(0, 40, 3):
+        one = {k: v[r:r + 1] for k, v in tbl.items()}
+        hapi.storage2cache_from_columns("one", one)
+        for T, p in ((296.0, 1.0), (220.0, 0.02)):
+            _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="one", Environment={"T": T, "p": p}, OmegaGrid=grid)
+            _, xr = ref.absorptionCoefficient_Voigt(one, T=T, p=p, OmegaGrid=grid)
+            assert np.array_equal(xs != 0, xr != 0)
+            assert rel_err(xs, xr) <= TOL_L
+
+
+def test_voigt_doppler_regime_vs_oracle(hapi):
+    """Low pressure / high wavenumber: y << 1, most of the window inside the Weideman region."""
+    tbl = synthetic.synth_line_table(5, 300, 4990.0, 5010.0)
+    hapi.storage2cache_from_columns("dop", tbl)
+    grid = np.linspace(4995.0, 5005.0, 50000)
+    for T, p in ((250.0, 1e-3), (296.0, 0.05), (200.0, 1e-5)):
+        _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="dop", Environment={"T": T, "p": p}, OmegaGrid=grid)
+        _, xr = ref.absorptionCoefficient_Voigt(tbl, T=T, p=p, OmegaGrid=grid)
+        assert rel_err(xs, xr) <= TOL_L, (T, p)
+
+
+def test_voigt_edge_cases(hapi):
+    tbl = synthetic.synth_line_table(3, 50, 900.0, 1100.0)
+    hapi.storage2cache_from_columns("e", tbl)
+    # grid entirely away from every line: exact zeros
+    g0 = np.linspace(3000.0, 3001.0, 777)
+    _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="e", OmegaGrid=g0)
+    assert xs.shape == (777,) and np.all(xs == 0)
+    # ragged size (not a multiple of any tile), lines left and right of the grid, tiny grid
+    for n in (2, 63, 257, 2049, 5001):
+        g1 = np.linspace(990.0, 1010.0, n)
+        _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="e", OmegaGrid=g1)
+        _, xr = ref.absorptionCoefficient_Voigt(tbl, OmegaGrid=g1)
+        assert rel_err(xs, xr) <= TOL_L, n
+    # Components filter that selects nothing -> zeros; unknown table / component -> exceptions like hapi
+    _, xs = hapi.absorptionCoefficient_Voigt(Components=[(5, 1)], SourceTables="e", OmegaGrid=g1)
+    assert np.all(xs == 0)
+    with pytest.raises(Exception):
+        hapi.absorptionCoefficient_Voigt(SourceTables="nope", OmegaGrid=g1)
+    with pytest.raises(Exception):
+        hapi.absorptionCoefficient_Voigt(Components=[(99, 1)], SourceTables="e", OmegaGrid=g1)
+    with pytest.raises(Exception):  # TIPS range (:9571)
+        hapi.absorptionCoefficient_Voigt(SourceTables="e", Environment={"T": 50.0, "p": 1.0}, OmegaGrid=g1)
+    # OmegaRange/OmegaStep path (arange_) and IntensityThreshold
+    om, xs = hapi.absorptionCoefficient_Voigt(SourceTables="e", OmegaRange=(995.0, 1005.0), OmegaStep=0.01, IntensityThreshold=1e-22)
+    _, xr = ref.absorptionCoefficient_Voigt(tbl, OmegaGrid=om, IntensityThreshold=1e-22)
+    assert om.size == 1001 and rel_err(xs, xr) <= TOL_L
+
+
+# ----------------------------------------------------------------------- G5 compute_OD / compute_TUD
+def _g5(golden):
+    g = golden("g5_tud_windows.npz")
+    full = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    return g, full, synthetic.c3_atmosphere(32), float(g["pad"])
+
+
+@pytest.mark.parametrize("w", [0, 1, 2])
+def test_g5_compute_tud_golden(rt, golden, w):
+    g, full, a, pad = _g5(golden)
+    lo, hi = float(g[f"w{w}_lo"]), float(g[f"w{w}_hi"])
+    sub = synthetic.subset_table(full, lo - pad, hi + pad)
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, Altitudes=np.asarray([500]), theta_r=0, N_angle=30, **a)
+    assert np.array_equal(X, g[f"w{w}_X"])
+    assert tau.shape == Lu.shape == Ld.shape == X.shape
+    assert np.max(np.abs(tau - g[f"w{w}_tau"])) <= TOL_TAU
+    assert rel_err(Lu, g[f"w{w}_Lu"]) <= TOL_L
+    assert rel_err(Ld, g[f"w{w}_Ld"]) <= TOL_L
+    # per-layer optical depth through compute_OD (layer 1 and layer 32)
+    for k in (0, 31):
+        Xo, od = rt.compute_OD(lo, hi, DVOUT=0.001, line_table=sub, T=a["Ts"][k], P=a["Ps"][k], PL=a["PLs"][k],
+                               MF_VAL=a["MFs_VAL"][k], MF_ID=a["MFs_ID"])
+        assert np.array_equal(Xo, X)
+        assert rel_err(od, g[f"w{w}_OD"][:, k]) <= TOL_L
+
+
+def test_g5_compute_tud_quirks_golden(rt, golden):
+    g, full, a, pad = _g5(golden)
+    lo, hi = float(g["w1_lo"]), float(g["w1_hi"])
+    sub = synthetic.subset_table(full, lo - pad, hi + pad)
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, theta_r=0.6, Altitudes=np.asarray([1.0, 4.05, 9.0]),
+                                    N_angle=7, **a)
+    assert tau.shape == (X.size, 3) and Lu.shape == (X.size, 3)
+    assert np.max(np.abs(tau - g["w1_tau_alt"])) <= TOL_TAU
+    assert rel_err(Lu, g["w1_Lu_alt"]) <= TOL_L
+    assert rel_err(Ld, g["w1_Ld_alt"]) <= TOL_L
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, Altitudes=np.asarray([9.0]), returnOD=True, **a)
+    assert rel_err(tau, g["w1_tau_rod"]) <= TOL_L  # sum(OD*mu) in the tau slot
+    assert rel_err(Lu, g["w1_Lu_rod"]) <= TOL_L
+    assert rel_err(Ld, g["w1_Ld_rod"]) <= TOL_L
+
+
+def test_compute_tud_options_do_not_leak(rt, golden):
+    """Divergence from quirk 2, on purpose: kwargs must not persist in the module-level options."""
+    before = rt.options["DVOUT"]
+    g, full, a, pad = _g5(golden)
+    sub = synthetic.subset_table(full, 488.0, 514.0)
+    rt.compute_TUD(500.0, 500.5, DVOUT=0.01, line_table=sub, **a)
+    assert rt.options["DVOUT"] == before and rt.options["line_table"] is None
+    with pytest.raises(Exception):
+        rt.compute_TUD(500.0, 500.5, DVOUT=0.01)  # no line table configured
+
+
+def test_tud_66_layers_vs_oracle(rt):
+    """All 66 rows of the standard atmosphere (0-100 km: Doppler-dominated upper layers, NL=96 kernel)."""
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    lo, hi = 2300.0, 2300.8
+    sub = synthetic.subset_table(full, lo - 12.0, hi + 12.0)
+    A = synthetic.load_standard_atmosphere()
+    a = dict(Zs=A[:, 1], Ts=A[:, 5], Ps=A[:, 4], PLs=A[:, 3], MFs_VAL=A[:, 6:8] * 1e6, MFs_ID=np.array([1, 2]))
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.0005, line_table=sub, **a)
+    Xr, tau_r, Lu_r, Ld_r = ref.compute_TUD(sub, lo, hi, 0.0005, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    assert np.array_equal(X, Xr)
+    assert np.max(np.abs(tau - tau_r)) <= TOL_TAU
+    assert rel_err(Lu, Lu_r) <= TOL_L
+    assert rel_err(Ld, Ld_r) <= TOL_L
+
+
+# ------------------------------------------------------------------------------ G6 apparent radiance
+def test_g6_apparent_radiance_golden(rt, golden):
+    g = golden("g6_apparent_radiance.npz")
+    L0 = rt.compute_LWIR_apparent_radiance(g["X"], g["emis"], g["Ts"], g["tau"], g["La"], g["Ld"])
+    assert L0.shape == g["L0"].shape
+    assert rel_err(L0, g["L0"]) <= TOL_L
+    L1, Ls1 = rt.compute_LWIR_apparent_radiance(g["X"], g["emis"], g["Ts"], g["tau"], g["La"], g["Ld"], dT=g["dT"], return_Ls=True)
+    assert L1.shape == g["L1"].shape == (128, 9, 3, 9)
+    assert rel_err(L1, g["L1"]) <= TOL_L
+    assert rel_err(Ls1, g["Ls1"]) <= TOL_L
+    # the reference caller's own usage: float32 inputs (Compute_LWIR_Apparent_Radiance.py:9-20)
+    f = lambda k: g[k].astype(np.float32)
+    L32 = rt.compute_LWIR_apparent_radiance(f("X"), f("emis"), f("Ts"), f("tau"), f("La"), f("Ld"), dT=g["dT"])
+    assert L32.dtype == np.float32 and rel_err(L32, g["L1"]) <= 5e-6 + TOL_L
+
+
+# ------------------------------------------------------------------------------------------ G7 ILS
+def test_g7_ils_golden(rt, golden):
+    from radtxfr_amd import ILS_MAKO as ilsg
+    g = golden("g7_ils.npz")
+    X = np.linspace(float(g["X_lo"]), float(g["X_hi"]), int(g["X_n"]))
+    Y2 = g["Y2"]
+    xo, yo = rt.ILS_MAKO(X, Y2[:, 0])
+    assert np.array_equal(xo, g["xo1"]) and yo.shape == g["yo1"].shape
+    assert rel_err(yo, g["yo1"]) <= TOL_L
+    xo, yo = rt.ILS_MAKO(X, Y2)
+    assert yo.shape == g["yo2"].shape and rel_err(yo, g["yo2"]) <= TOL_L
+    xo, yo = rt.ILS_MAKO(X, Y2, resFactor=2)
+    assert np.array_equal(xo, g["xo3"]) and rel_err(yo, g["yo3"]) <= TOL_L
+    yo = rt.ILS_MAKO(X, Y2, returnX=False, fwhm_sf=1.3, shift=0.4, scale=1.0005)
+    assert rel_err(yo, g["yo4"]) <= TOL_L
+    xg, yg = ilsg.ILS_MAKO(X, Y2[:, 0])
+    assert np.array_equal(xg, g["xg1"])
+    ok = np.isfinite(g["yg1"])
+    assert np.array_equal(np.isfinite(yg), ok) and rel_err(yg[ok], g["yg1"][ok]) <= TOL_L
+    xg, yg = ilsg.ILS_MAKO(X, Y2)
+    ok = np.isfinite(g["yg2"])
+    assert np.array_equal(np.isfinite(yg), ok) and rel_err(yg[ok], g["yg2"][ok]) <= TOL_L
+
+
+def test_ils_many_spectra_and_edges(rt):
+    rng = np.random.default_rng(11)
+    X = np.linspace(760.0, 1320.0, 9000)
+    Y = rng.uniform(0.0, 10.0, (X.size, 130)).astype(np.float32)  # column kernel, ragged nS
+    xo, yo = rt.ILS_MAKO(X, Y)
+    xr, yr = ref.ILS_MAKO(X, Y.astype(np.float64))
+    assert np.array_equal(xo, xr) and yo.dtype == np.float32
+    assert rel_err(yo, yr) <= TOL_L
+    # coarse axis: some triangles catch no grid point -> NaN exactly where the reference has NaN (quirk 13)
+    Xc = np.linspace(760.0, 1320.0, 40)
+    Yc = rng.uniform(0, 1, Xc.size)
+    xo, yo = rt.ILS_MAKO(Xc, Yc)
+    with np.errstate(all="ignore"):
+        xr, yr = ref.ILS_MAKO(Xc, Yc)
+    assert np.array_equal(np.isnan(yo), np.isnan(yr))
+    ok = ~np.isnan(yr)
+    assert rel_err(yo[ok], yr[ok]) <= TOL_L
+
+
+# --------------------------------------------------------- size-independent properties at full size
+def test_full_c3_width_properties():
+    """5.5 M-point C3 grid x 32 layers at full size: properties that need no oracle run.
+    (1) linearity: OD with all mixing ratios doubled = 2 x OD;  (2) a wavenumber shard computes the
+    same numbers as the same slice of the full grid;  (3) tau = exp(-sum OD) consistency, 0<=tau<=1,
+    0 <= L-up,L-down <= max Planck;  (4) a sub-window equals the oracle."""
+    import torch
+    from radtxfr_amd import engine
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    a = synthetic.c3_atmosphere(32)
+    lines = engine.LineTable(full)
+    grid = engine.Grid(500.0, 6000.0, 5500000)
+    OD = engine.optical_depths(lines, grid, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    tau, Lu, Ld, _ = engine.tud(OD, grid, a["Ts"], a["Zs"])
+    torch.cuda.synchronize()
+    assert OD.shape == (32, 5500000) and bool(torch.isfinite(OD).all()) and float(OD.min()) >= 0.0
+    # (3)
+    s = OD.double().sum(0)
+    assert float((tau[0].double() - torch.exp(-s)).abs().max()) <= TOL_TAU
+    assert 0.0 <= float(tau.min()) and float(tau.max()) <= 1.0
+    Bmax = float(ref.planckian(np.array([500.0, 6000.0]), a["Ts"].max()).max())
+    for v in (Lu[0], Ld):
+        assert bool(torch.isfinite(v).all()) and float(v.min()) >= 0.0 and float(v.max()) <= Bmax * (1 + 1e-6)
+    # (1) on a shard, which also checks (2)
+    sh = grid.shard(2750000 - 1000, 40000 + 7)
+    OD1 = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    OD2 = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], 2.0 * a["MFs_VAL"], a["MFs_ID"])
+    ref_slice = OD[:, sh.offset:sh.offset + sh.n]
+    assert torch.equal(OD1, ref_slice), "wavenumber shard differs from the same slice of the full grid"
+    assert float(((OD2 - 2.0 * OD1).abs() / (2.0 * OD1).clamp_min(1e-30)).max()) <= 1e-6
+    # (4) oracle on a 3000-point window of the full grid
+    i0, n = 1234567, 3000
+    Xw = grid.axis()[i0:i0 + n]
+    sub = synthetic.subset_table(full, Xw[0] - 12.0, Xw[-1] + 12.0)
+    ODr = np.stack([ref.layer_od(sub, Xw, a["Ts"][k], a["Ps"][k], a["PLs"][k], a["MFs_VAL"][k], a["MFs_ID"]) for k in range(32)], 1)
+    tr, ur, dr = ref.tud_from_od(Xw, ODr, a["Ts"], a["Zs"])
+    assert rel_err(OD[:, i0:i0 + n].T.double().cpu().numpy(), ODr) <= TOL_L
+    assert np.max(np.abs(tau[0, i0:i0 + n].double().cpu().numpy() - tr)) <= TOL_TAU
+    assert rel_err(Lu[0, i0:i0 + n].double().cpu().numpy(), ur) <= TOL_L
+    assert rel_err(Ld[i0:i0 + n].double().cpu().numpy(), dr) <= TOL_L
+    lines.close()
