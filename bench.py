@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: wavenumber x layer points / s of the line-by-line LWIR hot path on config C3
+(BASELINE.json): 32-layer TUD (tau, L-up, L-down) from the standard atmosphere, 500-6000 cm^-1 at
+0.001 cm^-1 (5.5 M wavenumbers), synthetic 100 000-line H2O+CO2 HITRAN-format table.
+
+One step = one full pass: fp64 line prologue -> Voigt line-sum (OD[32][nX]) -> Planck + TUD
+integration (+ one RCCL all-gather of tau/L-up/L-down when the wavenumber axis is sharded over GPUs).
+Inputs (line table, atmosphere) are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline     -- dominant kernel (voigt_sum_kernel) algorithmic bytes / measured launch time vs 8 TB/s
+  cpu_baseline -- the NumPy oracle (port of the reference's CPU path) on a bounded sample, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+N_WAVENUMBERS = 5500000
+N_LINES = 100000
+N_LAYERS = 32
+
+
+def cpu_baseline(full_table, atm, seconds_hint=15.0):
+    """Oracle (kind 'port') on a bounded sample of the same workload: a 40 cm^-1 window of the C3 grid
+    (all 32 layers, the lines that can reach it), single process."""
+    from oracle import cpu_ref
+    from radtxfr_amd import synthetic
+    X = np.linspace(500.0, 6000.0, N_WAVENUMBERS)
+    i0, n = 2500000, 40000
+    Xw = X[i0:i0 + n]
+    sub = synthetic.subset_table(full_table, Xw[0] - 12.0, Xw[-1] + 12.0)
+    t0 = time.perf_counter()
+    OD = np.stack([cpu_ref.layer_od(sub, Xw, atm["Ts"][k], atm["Ps"][k], atm["PLs"][k], atm["MFs_VAL"][k], atm["MFs_ID"])
+                   for k in range(N_LAYERS)], axis=1)
+    cpu_ref.tud_from_od(Xw, OD, atm["Ts"], atm["Zs"])
+    dt = time.perf_counter() - t0
+    return {"value": n * N_LAYERS / dt, "unit": "wavenumber*layer points/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of {N_WAVENUMBERS} wavenumbers ({Xw[0]:.1f}-{Xw[-1]:.1f} cm^-1) x {N_LAYERS} layers, "
+                      f"{sub['nu'].size} lines in reach, NumPy fp64 oracle, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from radtxfr_amd import _lib, engine, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    _lib.load()
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # ---- inputs, resident in HBM before timing --------------------------------------------------
+    full = synthetic.synth_line_table(synthetic.SEED_C3, N_LINES, 475.0, 6025.0)
+    atm = synthetic.c3_atmosphere(N_LAYERS)
+    grid_full = engine.Grid(500.0, 6000.0, N_WAVENUMBERS)
+    per = (N_WAVENUMBERS + world - 1) // world
+    off = rank * per
+    n_loc = max(0, min(per, N_WAVENUMBERS - off))
+    grid = grid_full.shard(off, n_loc)
+    # each rank only needs the lines whose wings can reach its shard
+    if world > 1:
+        reach = engine.max_wing_cm(full, atm["Ts"], atm["Ps"] / 101325.0) + 1.0
+        xs = grid.axis()
+        table = synthetic.subset_table(full, xs[0] - reach, xs[-1] + reach)
+    else:
+        table = full
+    lines = engine.LineTable(table)
+    T, Z = atm["Ts"], atm["Zs"]
+    w, p_atm = engine.layer_weights_od(lines.species, T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
+    qratio, mass = engine.species_factors(lines.species, T)
+    dev = torch.device("cuda", local)
+    OD = torch.empty((N_LAYERS, n_loc), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, 3, per), dtype=torch.float32, device=dev) if world > 1 else None
+    packed = torch.zeros((3, per), dtype=torch.float32, device=dev) if world > 1 else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    t_voigt, t_tud = [], []
+
+    def step(record=False):
+        if record:
+            ev[0].record()
+        engine.voigt_sum(lines, grid, T, p_atm, w, out_f32=OD, qratio=qratio, mass=mass)
+        if record:
+            ev[1].record()
+        tau, Lu, Ld, _ = engine.tud(OD, grid, T, Z)
+        if record:
+            ev[2].record()
+        if world > 1:
+            packed[0, :n_loc], packed[1, :n_loc], packed[2, :n_loc] = tau[0], Lu[0], Ld
+            dist.all_gather_into_tensor(gathered, packed)
+        return tau, Lu, Ld
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- per-kernel launch time of the dominant kernel, HIP events on the launch stream ----------
+    for _ in range(min(args.steps, 5)):
+        step(record=True)
+        torch.cuda.synchronize()
+        t_voigt.append(ev[0].elapsed_time(ev[1]))  # prologue + tile ranges + voigt_sum_kernel
+        t_tud.append(ev[1].elapsed_time(ev[2]))
+    # isolate voigt_sum_kernel: time the prologue alone and subtract
+    lib = _lib.load()
+    t_prep = []
+    import ctypes as C
+    plan = lines.plan(N_LAYERS, n_loc)
+    hp = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.c_void_p)
+    keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (T, p_atm, qratio, w, mass)]
+    for _ in range(3):
+        ev[0].record()
+        _lib.check(lib.rtx_line_prep(plan._h, lines._h, grid.byref(), N_LAYERS, *[k.ctypes.data_as(C.c_void_p) for k in keep],
+                                     1.0, 0.0, 0.0, 50.0, 0.0, 1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ev[1].record()
+        torch.cuda.synchronize()
+        t_prep.append(ev[0].elapsed_time(ev[1]))
+    ms_voigt = float(np.median(t_voigt) - np.median(t_prep))
+    ms_tud = float(np.median(t_tud))
+
+    if rank == 0:
+        pts = float(N_WAVENUMBERS) * N_LAYERS
+        # algorithmic bytes of one voigt_sum_kernel launch (SURVEY 8d stage A): 4 B OD write per point
+        # + one 32 B fp32 line record per (line, layer)
+        alg_bytes = 4.0 * n_loc * N_LAYERS + 32.0 * lines.n * N_LAYERS
+        achieved = alg_bytes / (ms_voigt * 1e-3) / 1e9
+        name = ""
+        try:
+            buf = C.create_string_buffer(128)
+            ncu = C.c_int(0)
+            lib.rtx_device_info(buf, 128, C.byref(ncu))
+            name = buf.value.decode()
+        except Exception:
+            pass
+        out = {
+            "metric": "wavenumber*layer points/s (32-layer TUD, 500-6000 cm^-1 @ 0.001 cm^-1)",
+            "value": pts * args.steps / dt, "unit": "wavenumber*layer points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C3: 32-layer TUD (tau,Lu,Ld) StandardAtmosphere rows 1-32, 500-6000 cm^-1 @ 0.001 cm^-1",
+                       "n_wavenumbers": N_WAVENUMBERS, "n_layers": N_LAYERS, "n_lines": N_LINES, "n_angles": 30,
+                       "line_table": "synthetic HITRAN-format H2O+CO2, seed 20261005",
+                       "parallelism": f"wavenumber-sharded x{world}" + (" + 1 RCCL all-gather" if world > 1 else "")},
+            "roofline": {"kernel": "voigt_sum_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "ms_per_launch": ms_voigt, "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "VALU/transcendental-bound by construction (SURVEY 8d): ~10 fp32 ops + 1 rcp per "
+                                 "line-point evaluation; see DESIGN.md for the VALU roofline",
+                         "other_kernels_ms": {"line_prep_kernel": float(np.median(t_prep)), "tud_kernel": ms_tud}},
+            "device": name,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(full, atm)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    lines.close()
+
+
+if __name__ == "__main__":
+    main()

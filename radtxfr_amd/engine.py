@@ -296,3 +296,21 @@ def ils(kind, Y, centre, sigma, X=None, grid=None):
     _lib.check(lib.rtx_ils(int(kind), grid.byref() if grid is not None else None, _ptr(X), nx, _ptr(Y), nS, Y.stride(0),
                            nB, _ptr(centre), _ptr(sigma), _ptr(out), _stream_ptr()))
     return out
+
+
+def max_wing_cm(columns, T_layers, p_atm_layers, omega_wing=0.0, omega_wing_hw=50.0):
+    """Upper bound [cm^-1] of OmegaWingF (misc/hapi.py:11131) over all lines and layers, plus the largest
+    pressure shift: how far outside a wavenumber shard a line centre can sit and still contribute.
+    Used to give each GPU only the lines that can reach its shard."""
+    T = np.asarray(T_layers, dtype=np.float64)
+    p = np.asarray(p_atm_layers, dtype=np.float64)
+    nu = np.asarray(columns["nu"], dtype=np.float64)
+    if nu.size == 0:
+        return float(omega_wing)
+    g = float(np.max(columns["gamma_air"]))
+    n_hi, n_lo = float(np.max(columns["n_air"])), float(np.min(columns["n_air"]))
+    tr = TREF / T
+    g0 = g * np.max(p * np.maximum(tr ** n_hi, tr ** n_lo))
+    gd = 3.6e-7 * float(np.max(nu)) * np.sqrt(float(np.max(T)) / 1.0)  # mass >= 1 g/mol: generous
+    shift = float(np.max(np.abs(columns["delta_air"]))) * float(np.max(p))
+    return max(float(omega_wing), omega_wing_hw * g0, omega_wing_hw * min(gd, 10.0 * g0 + 1.0)) + shift

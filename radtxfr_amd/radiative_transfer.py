@@ -64,13 +64,13 @@ def _is_torch(x):
 def _dev_f64(x, dev):
     if _is_torch(x):
         return x.to(device=dev, dtype=torch.float64).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=dev)
+    return torch.as_tensor(np.asarray(x, dtype=np.float64), device=dev).contiguous()
 
 
 def _dev_f32(x, dev):
     if _is_torch(x):
         return x.to(device=dev, dtype=torch.float32).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=dev)
+    return torch.as_tensor(np.asarray(x, dtype=np.float32), device=dev).contiguous()
 
 
 def make_spectral_axis(Xmin, Xmax, DVOUT):
