@@ -26,5 +26,8 @@ def rel_err(a, ref, floor_frac=1e-3):
     """SURVEY 8d metric: max |a-ref| / max(|ref|, floor_frac*max|ref|)."""
     a = np.asarray(a, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
-    den = np.maximum(np.abs(ref), floor_frac * np.max(np.abs(ref)))
+    mx = np.max(np.abs(ref)) if ref.size else 0.0
+    if mx == 0.0:  # all-zero reference: any non-zero is an infinite relative error
+        return 0.0 if not np.any(a) else float("inf")
+    den = np.maximum(np.abs(ref), floor_frac * mx)
     return float(np.max(np.abs(a - ref) / den))
