@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradtxfr_hip.so")
+# RADTXFR_LIB: developer override to A/B-test another build of the same ABI (tools/time_c3.py)
+LIB_PATH = os.environ.get("RADTXFR_LIB") or os.path.join(_HERE, "libradtxfr_hip.so")
 
 
 class RtxGrid(C.Structure):

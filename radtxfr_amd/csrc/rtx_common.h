@@ -45,16 +45,21 @@ __device__ __forceinline__ double grid_x(const GridDev& g, long long ig) {
 }
 
 // ---- per-(line,layer) records written by the prologue, read by the line-sum --------------------
-// fp32 record (32 B): everything the asymptotic (far-wing) evaluation needs, relative to the grid.
+// fp32 record (48 B): everything the asymptotic (far-wing) evaluation needs, relative to the grid.
+// x(i) = (i - i0)*a + c ;  contribution = (xx*Ay + Ay0) / ((xx + b1)*xx + b0),  xx = x*x.
 struct __attribute__((aligned(16))) LineRec {
-  float a;   // x per grid index = step*cte,  cte = sqrt(ln2)/GammaD
-  float c;   // x at grid index i0            = (X[i0]-nu0')*cte
-  float y;   // Gamma0*cte
-  float A;   // weight*S(T)*cte/sqrt(pi)*scale  (strength times the profile's prefactor)
-  int i0;    // LOCAL grid index nearest to the shifted centre nu0' (may lie outside [0,n))
-  int lo;    // window = local indices [lo,hi): bisect(X,nu0-W), bisect(X,nu0+W) clipped to the shard
+  float a;    // x per grid index = step*cte,  cte = sqrt(ln2)/GammaD
+  float c;    // x at grid index i0            = (X[i0]-nu0')*cte
+  float b1;   // 2y^2 - 1,        y = Gamma0*cte
+  float b0;   // (y^2 + 1/2)^2
+  float Ay;   // A*y/sqrt(pi)
+  float Ay0;  // Ay*(y^2 + 1/2)
+  float y;    // for the fp32 Weideman branch
+  float A;    // weight*S(T)*cte/sqrt(pi)*scale  (strength times the profile's prefactor)
+  int i0;     // LOCAL grid index nearest to the shifted centre nu0' (may lie outside [0,n))
+  int lo;     // window = local indices [lo,hi): bisect(X,nu0-W), bisect(X,nu0+W) clipped to the shard
   int hi;
-  int zw;    // half-width, in grid points, of the band around i0 that can hold |x|+y<15 (0: none)
+  int zw;     // half-width, in grid points, of the band around i0 that can hold |x|+y<15 (0: none)
 };
 // fp64 companion (32 B), read only where the Weideman region is entered.
 struct __attribute__((aligned(16))) LineRec64 {
@@ -80,6 +85,7 @@ struct rtx_prep {
   int* ic;             // [n_lines] local grid index nearest the UNSHIFTED centre (sorted)
   int* maxhw;          // [max_layers] max window half-width in grid points (+margin)
   int2* ranges;        // [max_layers][max_tiles] candidate line range per line-sum tile
+  int* smally;         // [max_layers] set when a line of that layer has a Weideman band with y < 1
   long long max_tiles;
   double* env;         // device copy of T,p,qratio,weight,mass (packed)
   size_t env_cap;

@@ -117,6 +117,7 @@ extern "C" int rtx_prep_free(rtx_prep* P) {
   if (P->maxhw) (void)hipFree(P->maxhw);
   if (P->env) (void)hipFree(P->env);
   if (P->ranges) (void)hipFree(P->ranges);
+  if (P->smally) (void)hipFree(P->smally);
   delete P;
   return 0;
 }
@@ -142,6 +143,7 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
   if (e == hipSuccess) e = hipMalloc((void**)&P->ic, sizeof(int) * (size_t)(lines->n > 0 ? lines->n : 1));
   if (e == hipSuccess) e = hipMalloc((void**)&P->maxhw, sizeof(int) * (size_t)max_layers);
   if (e == hipSuccess) e = hipMalloc((void**)&P->env, sizeof(double) * P->env_cap);
+  if (e == hipSuccess) e = hipMalloc((void**)&P->smally, sizeof(int) * (size_t)max_layers);
   if (e == hipSuccess) e = hipMalloc((void**)&P->ranges, sizeof(int2) * (size_t)P->max_tiles * (size_t)max_layers);
   if (e != hipSuccess) {
     rtx_set_error("rtx_prep_create: %s (%zu records)", hipGetErrorString(e), nrec);
@@ -172,6 +174,7 @@ struct PrepArgs {
   LineRec64* rec64;
   int* ic;
   int* maxhw;
+  int* smally;
 };
 
 // bisect.bisect (= bisect_right) of value v on the FULL grid: number of grid points <= v.
@@ -195,9 +198,11 @@ __device__ __forceinline__ int clamp_local(long long ig, const GridDev& g) {
   return (int)l;
 }
 
-__device__ __forceinline__ int sat_i32(long long v) {
-  const long long M = 1000000000LL;  // keeps i - i0 and i0 +- zw well inside int32
-  return (int)(v < -M ? -M : (v > M ? M : v));
+// Local centre index clamped to [-1e8, n+1e8]: with n <= 2e9 and zw <= 4e7 every i - i0, lo - i0 and
+// i0 +- zw the line-sum forms stays inside int32. A centre that far outside cannot reach the shard.
+__device__ __forceinline__ int sat_local(long long v, long long n) {
+  const long long M = 100000000LL;
+  return (int)(v < -M ? -M : (v > n + M ? n + M : v));
 }
 
 __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
@@ -255,18 +260,24 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     LineRec r;
     r.a = (float)ax;
     r.c = (float)frac_x;
+    const double yh = y * y + 0.5;
+    r.b1 = (float)(2.0 * (y * y) - 1.0);
+    r.b0 = (float)(yh * yh);
+    r.Ay = (float)(A * y * 0.56418958354775628);
+    r.Ay0 = (float)(A * y * 0.56418958354775628 * yh);
     r.y = (float)y;
     r.A = (float)A;
-    r.i0 = sat_i32(gi0 - g.offset);
+    r.i0 = sat_local(gi0 - g.offset, g.n);
     r.lo = lo;
     r.hi = hi;
     // half-width (grid points) of the band that can satisfy |x|+y<15 (hum1_wei switch, misc/hapi.py:9840)
     int zw = 0;
     if (y < 15.0 && hi > lo) {
       double z = ceil((15.0 - y) / ax) + 2.0;
-      zw = z > 1.0e9 ? 1000000000 : (int)z;
+      zw = z > 4.0e7 ? 40000000 : (int)z;
     }
     r.zw = zw;
+    if (zw > 0 && r.y < 1.0f) a.smally[k] = 1;  // benign race: every writer stores 1
     LineRec64 r64;
     r64.sg0 = sg0; r64.cte = cte; r64.y = y; r64.A = A;
     const size_t o = (size_t)k * (size_t)a.n_lines + (size_t)l;
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       long long gic = llrint((nu - g.xmin) / g.step);
       if (gic < -M) gic = -M;
       if (gic > M) gic = M;
-      a.ic[l] = sat_i32(gic - g.offset);
+      a.ic[l] = sat_local(gic - g.offset, g.n);
     }
     if (hi > lo) {
       // window half-width in grid points, measured from the unshifted centre, with margin
@@ -319,6 +330,7 @@ extern "C" int rtx_line_prep(rtx_prep* P, const rtx_lines* L, const rtx_grid* gr
   RTX_HIP(hipMemcpyAsync(d + 2 * nT + nQ, weight_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
   RTX_HIP(hipMemcpyAsync(d + 2 * nT + 2 * nQ, mass_h, ns * sizeof(double), hipMemcpyHostToDevice, st));
   RTX_HIP(hipMemsetAsync(P->maxhw, 0, sizeof(int) * (size_t)n_layers, st));
+  RTX_HIP(hipMemsetAsync(P->smally, 0, sizeof(int) * (size_t)n_layers, st));
   P->n_layers = n_layers;
   P->scale = scale;
   if (L->n == 0) return 0;
@@ -331,7 +343,7 @@ extern "C" int rtx_line_prep(rtx_prep* P, const rtx_lines* L, const rtx_grid* gr
   a.dil_air = dil_air; a.dil_self = dil_self; a.omega_wing = omega_wing; a.omega_wing_hw = omega_wing_hw;
   a.thresh = intensity_threshold; a.scale = scale;
   a.g = to_dev(grid);
-  a.rec = P->rec; a.rec64 = P->rec64; a.ic = P->ic; a.maxhw = P->maxhw;
+  a.rec = P->rec; a.rec64 = P->rec64; a.ic = P->ic; a.maxhw = P->maxhw; a.smally = P->smally;
   dim3 grd((unsigned)((L->n + 255) / 256), (unsigned)n_layers);
   hipLaunchKernelGGL(line_prep_kernel, grd, dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();

@@ -3,13 +3,19 @@
 // hum1_wei :9833-9844).
 //
 // Mapping (CDNA4): one workgroup = 4 waves = one tile of 4*64*P consecutive grid points of one layer.
-// Lane <-> grid point (coalesced along the wavenumber axis), each lane owns P points 64 apart, so
-// a "row" of 64 consecutive points is one wave-instruction wide and every per-line decision
-// (window edge, Weideman zone) is wave-uniform per row -- no divergence inside a row.
-// The lines that can reach the tile are culled, order-preserving, into LDS by the whole workgroup
-// (ballot + prefix), then every wave walks the LDS list with broadcast reads.
+// Lane <-> grid point (coalesced along the wavenumber axis), each lane owns P points 64 apart, so a
+// "row" of 64 consecutive points is one wave-instruction wide and every per-line decision (window
+// edge, Weideman zone) is wave-uniform per row -- no divergence inside a row.
 //
-// Arithmetic: the far-wing branch of hum1_wei (|x|+y >= 15; >95 % of evaluations in the troposphere)
+// Staging: the 256 threads fetch 256 candidate line records into LDS and classify each one against
+// each of the 4 wave spans IN PARALLEL (vector code): 0 = does not reach the wave, 1 = the wave lies
+// wholly inside the line's window and outside its Weideman band ("fast"), 2 = anything else. Ballots
+// and prefix counts turn that into one order-preserving index list per wave. The wave loop then
+// only visits lines it needs and spends no scalar instructions on classification -- the first
+// version of this kernel did those tests per (line, wave) in scalar code and was bound by the CU's
+// single scalar ALU (rocprof: 0.75 SALU per VALU instruction), not by the vector pipes.
+//
+// Arithmetic: the far-wing branch of hum1_wei (|x|+y >= 15; ~99 % of evaluations in the troposphere)
 // is evaluated in fp32 from a grid-relative argument (integer index difference times step*cte plus
 // a sub-grid residual), which keeps (nu - nu0) exact to ~1e-7 relative; the region test and the
 // Weideman-24 branch use the fp64 record (fp64 polynomial when y<1, where fp32 loses Re w).
@@ -25,27 +31,28 @@ __device__ __forceinline__ F weideman_re(F x, F y, const F* __restrict__ coef) {
   // d = L - i z = (L+y) - i x ;  n = L + i z = (L-y) + i x ;  Z = n/d
   const F dr = L + y, di = -x;
   const F nr = L - y, ni = x;
-  const F inv = (F)1 / (dr * dr + di * di);
-  const F Zr = (nr * dr + ni * di) * inv;
-  const F Zi = (ni * dr - nr * di) * inv;
+  const F inv = (F)1 / fma(dr, dr, di * di);
+  const F Zr = fma(nr, dr, ni * di) * inv;
+  const F Zi = fma(ni, dr, -(nr * di)) * inv;
   F pr = coef[0], pi = (F)0;
 #pragma unroll
-  for (int k = 1; k < 24; ++k) {
-    const F tr = pr * Zr - pi * Zi + coef[k];
-    const F ti = pr * Zi + pi * Zr;
+  for (int k = 1; k < 24; ++k) {  // Horner in Z, 4 FMA per step
+    const F tr = fma(pr, Zr, fma(-pi, Zi, coef[k]));
+    const F ti = fma(pr, Zi, pi * Zr);
     pr = tr;
     pi = ti;
   }
   // 1/d = conj(d)*inv ; w = 2 p /d^2 + (1/sqrt(pi))/d
   const F ir = dr * inv, ii = -di * inv;
-  const F i2r = ir * ir - ii * ii, i2i = (F)2 * ir * ii;
-  return (F)2 * (pr * i2r - pi * i2i) + (F)INV_SQRT_PI * ir;
+  const F i2r = fma(ir, ir, -(ii * ii)), i2i = (F)2 * ir * ii;
+  return fma((F)2, fma(pr, i2r, -(pi * i2i)), (F)INV_SQRT_PI * ir);
 }
 
 struct VsArgs {
   const LineRec* rec;      // [n_layers][n_lines]
   const LineRec64* rec64;  // [n_layers][n_lines]
   const int2* ranges;      // [n_layers][n_tiles] candidate line range per tile
+  const int* smally;       // [n_layers] != 0: some line has a Weideman band with y < 1 (fp64 pass needed)
   long long n_lines;
   int n_tiles;
   int tiles_per_xcd;
@@ -75,8 +82,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
   if (ib > a.n) ib = a.n;
   const long long hw = a.maxhw[k];
   const long long vlo = ia - hw, vhi = ib - 1 + hw;
-  // lower_bound(ic, vlo)
-  long long lo = 0, hi = a.n_lines;
+  long long lo = 0, hi = a.n_lines;  // lower_bound(ic, vlo)
   while (lo < hi) {
     long long mid = (lo + hi) >> 1;
     if ((long long)a.ic[mid] < vlo) lo = mid + 1; else hi = mid;
@@ -90,14 +96,28 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
   a.ranges[(size_t)k * a.n_tiles + t] = make_int2((int)l0, (int)lo);
 }
 
-template <int P>
+// One far-wing evaluation: Re[(1/sqrt(pi)) t/(1/2+t^2)], t = y - i x  (hum1_wei, :9834-9835) times the
+// line strength, as  (xx*Ay + Ay0) / ((xx + b1)*xx + b0)  with per-line constants from the fp64 prologue;
+// x = u*a + c with u = i - i0 an exact integer-valued float.  7 full-rate VALU ops + 1 v_rcp_f32.
+#define RTX_FARWING(u_, q_, num_, rden_)                      \
+  const float x_ = fmaf((u_), (q_).a, (q_).c);                \
+  const float xx_ = x_ * x_;                                  \
+  float num_ = fmaf(xx_, (q_).Ay, (q_).Ay0);                  \
+  float rden_ = __builtin_amdgcn_rcpf(fmaf(xx_ + (q_).b1, xx_, (q_).b0))
+
+// CORE64 = false: the main pass. Far wing everywhere, fp32 Weideman inside the bands of lines with y >= 1.
+// CORE64 = true : a second, usually empty, pass that ADDS the band points of lines with y < 1
+//                 (Doppler-dominated: stratosphere, low pressure), where Re w needs the fp64 polynomial.
+//                 Keeping that code out of the main kernel keeps it at ~64 VGPRs (the fp64 Horner
+//                 chain costs 140 and drops the occupancy of the whole line loop to 3 waves/SIMD).
+template <int P, bool CORE64>
 __global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
   constexpr int WPTS = 64 * P;    // points per wave
   constexpr int TILE = 4 * WPTS;  // points per workgroup
-  constexpr int CHUNK = 256;
+  constexpr int CHUNK = 256;      // candidates staged per round (one per thread)
   __shared__ LineRec s_rec[CHUNK];
-  __shared__ int s_idx[CHUNK];
-  __shared__ int s_wcount[4];
+  __shared__ int s_list[4][CHUNK + 2];  // per consuming wave: (class << 8 | slot), order-preserving; +2 prefetch slack
+  __shared__ int s_cnt[4][4];           // [staging wave][consuming wave]
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
   // contiguous run of tiles -- neighbouring tiles share most of their line records in that XCD's L2.
@@ -105,117 +125,167 @@ __global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
   const int tile = (b & 7) * a.tiles_per_xcd + (b >> 3);
   if (tile >= a.n_tiles) return;  // whole workgroup exits together
   const int k = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (CORE64 && a.smally[k] == 0) return;
+  // readfirstlane makes the wave index an SGPR, so the per-line control flow below is scalar code
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
   const long long n = a.g.n;
   const int ia = tile * TILE;
   const int ib = (int)((long long)ia + TILE < n ? (long long)ia + TILE : n);
   const int wa = ia + wave * WPTS;
-  const int wb = wa + WPTS < ib ? wa + WPTS : ib;  // may be <= wa for a tail wave: it then skips everything
   const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
   const LineRec64* __restrict__ rec64 = a.rec64 + (size_t)k * (size_t)a.n_lines;
   const int2 rng = a.ranges[(size_t)k * a.n_tiles + tile];
 
   float acc[P];
-  float lanef[P];
 #pragma unroll
-  for (int r = 0; r < P; ++r) {
-    acc[r] = 0.f;
-    lanef[r] = (float)(lane + 64 * r);
-  }
+  for (int r = 0; r < P; ++r) acc[r] = 0.f;
+  const float lanef = (float)lane;
+  bool touched = false;  // CORE64: did this wave add anything (wave-uniform)
 
   for (int base = rng.x; base < rng.y; base += CHUNK) {
-    // ---- stage: every thread fetches one candidate, keeps it if its window meets the tile ----
+    // ---- stage + classify (vector code, all 256 threads) ---------------------------------------
     const int l = base + (int)threadIdx.x;
-    LineRec r;
-    bool keep = false;
-    if (l < rng.y) {
-      r = rec[l];
-      keep = (r.lo < ib) && (r.hi > ia);
+    const bool valid = l < rng.y;
+    const float4* src = reinterpret_cast<const float4*>(rec + (valid ? l : rng.y - 1));  // 48-B record = 3 x 16 B
+    const float4 r0 = src[0], r1 = src[1];
+    const int4 r2 = reinterpret_cast<const int4*>(src)[2];  // i0, lo, hi, zw
+    {
+      float4* dst = reinterpret_cast<float4*>(&s_rec[threadIdx.x]);
+      dst[0] = r0;
+      dst[1] = r1;
+      reinterpret_cast<int4*>(dst)[2] = r2;
     }
-    const unsigned long long m = __ballot(keep);
-    const int pos = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wcount[wave] = __popcll(m);
-    __syncthreads();
-    int off = 0;
+    const int lo = r2.y, hi = r2.z;
+    const int zlo = r2.x - r2.w, zhi = r2.x + r2.w;  // band that can hold |x|+y<15 (zw = 0: none)
+    int cls[4], pos[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) off += (w < wave) ? s_wcount[w] : 0;
-    const int total = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-    if (keep) {
-      s_rec[off + pos] = r;
-      s_idx[off + pos] = l;
+    for (int w = 0; w < 4; ++w) {
+      const int wwa = ia + w * WPTS;
+      const int wwb = wwa + WPTS < ib ? wwa + WPTS : ib;
+      const bool band = (r2.w > 0) && (zhi >= wwa) && (zlo < wwb);
+      bool reach = valid && (hi > wwa) && (lo < wwb);  // empty windows have lo = hi = 0
+      if (CORE64) reach = reach && band && (r1.z < 1.0f);  // r1.z = y
+      const bool fast = (lo <= wwa) && (hi >= wwb) && !band;
+      cls[w] = reach ? (fast ? 1 : 2) : 0;
+      const unsigned long long m = __ballot(reach);
+      pos[w] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_cnt[wave][w] = __popcll(m);
     }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int off = 0;
+#pragma unroll
+      for (int sw = 0; sw < 4; ++sw) off += (sw < wave) ? s_cnt[sw][w] : 0;
+      if (cls[w]) s_list[w][off + pos[w]] = (cls[w] << 8) | (int)threadIdx.x;
+    }
+    const int total = s_cnt[0][wave] + s_cnt[1][wave] + s_cnt[2][wave] + s_cnt[3][wave];
     __syncthreads();
 
-    // ---- every wave walks the culled list (LDS broadcast reads) --------------------------------
-    for (int j = 0; j < total && wb > wa; ++j) {
-      const LineRec q = s_rec[j];
-      if (q.hi <= wa || q.lo >= wb) continue;  // wave-uniform
-      const bool inside = (q.lo <= wa) && (q.hi >= wb);
-      const bool zone = (q.zw > 0) && (q.i0 + q.zw >= wa) && (q.i0 - q.zw < wb);
-      // per-line constants of the asymptote  Re[(1/sqrt(pi)) t/(1/2+t^2)], t = y - i x  (:9834-9835):
-      //   = (1/sqrt(pi)) y (x^2+y^2+1/2) / (x^4 + x^2 (2y^2-1) + (y^2+1/2)^2)
-      const float y2 = q.y * q.y;
-      const float b1 = 2.f * y2 - 1.f;
-      const float yh = y2 + 0.5f;
-      const float b0 = yh * yh;
-      const float Ay = q.A * q.y * (float)INV_SQRT_PI;
-      const float Ay0 = Ay * yh;
-      const float kf = (float)((long long)wa - (long long)q.i0);  // exact: |wa - i0| < 2^24 for any sane window
-      if (inside && !zone) {
+    // ---- this wave's lines, in table order (LDS broadcast reads, software-prefetched) ----------
+    const int* __restrict__ list = s_list[wave];
+    int e_nxt = list[0];
+    LineRec q_nxt = s_rec[e_nxt & 255];
+    e_nxt = __builtin_amdgcn_readfirstlane(e_nxt);
+    int e_nn = list[1];
+    for (int j = 0; j < total; ++j) {
+      const LineRec q = q_nxt;
+      const int e = e_nxt;
+      e_nxt = __builtin_amdgcn_readfirstlane(e_nn);
+      q_nxt = s_rec[e_nxt & 255];  // garbage past the end of the list: never used
+      e_nn = list[j + 2];
+      // u = i - i0 as a float: integer-valued and exact while |i - i0| < 2^24 (any sane window);
+      // |i0| is clamped by the prologue, so wa - i0 cannot overflow int32
+      const float u0 = (float)(wa - __builtin_amdgcn_readfirstlane(q.i0)) + lanef;
+#ifndef RTX_ABLATE
+#define RTX_ABLATE 0  /* timing experiments only: 1 = no phase B, 2 = every visit takes the fast path, 3 = no math */
+#endif
+      if (RTX_ABLATE == 3) continue;
+      if (!CORE64 && ((e >> 8) == 1 || RTX_ABLATE == 2)) {
 #pragma unroll
         for (int r = 0; r < P; ++r) {
-          const float u = kf + lanef[r];  // integer-valued, exact
-          const float x = fmaf(u, q.a, q.c);
-          const float xx = x * x;
-          const float den = fmaf(xx + b1, xx, b0);
-          const float num = fmaf(xx, Ay, Ay0);
-          acc[r] = fmaf(num, __builtin_amdgcn_rcpf(den), acc[r]);
+          RTX_FARWING(u0 + (float)(64 * r), q, num, rden);
+          acc[r] = fmaf(num, rden, acc[r]);
         }
       } else {
-        // edge of the window and/or rows that may enter the Weideman region: row by row
+        // General case. Phase A: every row the window reaches, far-wing formula, lanes outside [lo,hi)
+        // or inside the Weideman band masked to zero (vector compares: no scalar work per row).
+        const int qlo = __builtin_amdgcn_readfirstlane(q.lo), qhi = __builtin_amdgcn_readfirstlane(q.hi);
+        const int qi0 = __builtin_amdgcn_readfirstlane(q.i0), qzw = __builtin_amdgcn_readfirstlane(q.zw);
+        const float ulo = (float)(qlo - qi0), uhi = (float)(qhi - qi0);
+        const float zw_f = qzw > 0 ? (float)qzw : -1.0f;  // |u| <= zw  <=>  inside the band
+        const int rb = qlo > wa ? (qlo - wa) >> 6 : 0;
+        const int re = ((qhi - 1 - wa) >> 6) + 1 < P ? ((qhi - 1 - wa) >> 6) + 1 : P;
+#pragma unroll
         for (int r = 0; r < P; ++r) {
-          const int ra = wa + 64 * r;
-          if (q.hi <= ra || q.lo >= ra + 64) continue;  // wave-uniform
-          const int i = ra + lane;
-          const bool in_win = (i >= q.lo) && (i < q.hi);
-          const float u = kf + (float)(lane + 64 * r);
-          const float x = fmaf(u, q.a, q.c);
-          const float xx = x * x;
-          // same num * rcp(den) + acc as the fast path, so a point gets the same bits whichever path
-          // (i.e. whichever tiling / wavenumber shard) reaches it
-          float num = fmaf(xx, Ay, Ay0);
-          float rden = __builtin_amdgcn_rcpf(fmaf(xx + b1, xx, b0));
-          const bool zrow = (q.zw > 0) && (q.i0 + q.zw >= ra) && (q.i0 - q.zw < ra + 64);
-          if (zrow) {
-            // region test exactly as the reference forms it (fp64): x = -Im Z1 = -((sg0 - sg)*cte)
-            const LineRec64 Q = rec64[s_idx[j]];
-            const double sg = grid_x(a.g, a.g.offset + (long long)i);
-            const double x64 = -((Q.sg0 - sg) * Q.cte);
-            const bool wz = (fabs(x64) + Q.y < 15.0);
-            if (wz) {
-              if (Q.y < 1.0)
+          if (CORE64 || r < rb) continue;
+          if (r >= re) break;
+          const float u = u0 + (float)(64 * r);
+          RTX_FARWING(u, q, num, rden);
+          num = (u >= ulo && u < uhi && !(fabsf(u) <= zw_f)) ? num : 0.f;
+          acc[r] = fmaf(num, rden, acc[r]);
+        }
+        // Phase B: the few rows around the line centre that hold band points. A line with y < 1 is
+        // left to the CORE64 pass (same predicate on the same fp32 record in both passes).
+        const bool small_y = q.y < 1.0f;
+        if (qzw > 0 && RTX_ABLATE != 1 && (CORE64 ? small_y : !small_y)) {
+          const int zlo_ = qi0 - qzw, zhi_ = qi0 + qzw;
+          const int first = (zlo_ > qlo ? zlo_ : qlo) - wa;
+          const int last = (zhi_ < qhi - 1 ? zhi_ : qhi - 1) - wa;
+          const int r0_ = first > 0 ? first >> 6 : 0;
+          const int r1_ = (last >> 6) < P - 1 ? (last >> 6) : P - 1;
+          for (int r = r0_; r <= r1_; ++r) {
+            const int i = wa + 64 * r + lane;
+            const float u = u0 + (float)(64 * r);
+            // same num * rcp(den) + acc as every other row, so a point gets the same bits whichever
+            // tiling (wavenumber shard) reaches it
+            RTX_FARWING(u, q, num, rden);
+            // hum1_wei's switch |x|+y < 15 (:9840). fp32 decides unless a lane sits within 2e-3 of the
+            // boundary (fp32 error of |x|+y is < 1e-5 here); those lanes repeat the test exactly as
+            // the reference forms it, in fp64: x = -Im Z1 = -((sg0 - sg)*cte).
+            const float s32 = fabsf(x_) + q.y;
+            bool wz = s32 < 15.0f;
+            const bool near = fabsf(s32 - 15.0f) < 2e-3f;
+            if (CORE64 || __ballot(near)) {
+              const LineRec64 Q = rec64[base + (e & 255)];
+              const double sg = grid_x(a.g, a.g.offset + (long long)i);
+              const double x64 = -((Q.sg0 - sg) * Q.cte);
+              const bool wz64 = fabs(x64) + Q.y < 15.0;
+              wz = (CORE64 || near) ? wz64 : wz;
+              if (CORE64 && wz) {
                 num = (float)(Q.A * weideman_re<double>(x64, Q.y, W24D));
-              else
-                num = q.A * weideman_re<float>((float)x64, q.y, W24F);
+                rden = 1.0f;
+              }
+            }
+            if (!CORE64 && wz) {
+              num = q.A * weideman_re<float>(x_, q.y, W24F);
               rden = 1.0f;
             }
-          }
-          num = in_win ? num : 0.f;
+            num = (u >= ulo && u < uhi && fabsf(u) <= zw_f) ? num : 0.f;
+            if (CORE64) touched = true;
 #pragma unroll
-          for (int rr = 0; rr < P; ++rr) acc[rr] = (rr == r) ? fmaf(num, rden, acc[rr]) : acc[rr];
+            for (int rr = 0; rr < P; ++rr) acc[rr] = (rr == r) ? fmaf(num, rden, acc[rr]) : acc[rr];
+          }
         }
       }
     }
     __syncthreads();
   }
 
+  if (CORE64 && !touched) return;
 #pragma unroll
   for (int r = 0; r < P; ++r) {
     const long long i = (long long)wa + 64 * r + lane;
-    if (i < (long long)wb) {
+    if (i < (long long)ib) {
       const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
-      if (a.out32) a.out32[o] = acc[r];
-      if (a.out64) a.out64[o] = (double)acc[r] * a.inv_scale;
+      if (CORE64) {  // read-modify-write by the owning lane only: deterministic
+        if (a.out32) a.out32[o] += acc[r];
+        if (a.out64) a.out64[o] += (double)acc[r] * a.inv_scale;
+      } else {
+        if (a.out32) a.out32[o] = acc[r];
+        if (a.out64) a.out64[o] = (double)acc[r] * a.inv_scale;
+      }
     }
   }
 }
@@ -250,11 +320,14 @@ extern "C" int rtx_voigt_sum(const rtx_prep* P, const rtx_grid* grid, int n_laye
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles + 255) / 256, n_layers), dim3(256), 0, st, ra);
   RTX_LAUNCH_CHECK();
   VsArgs a;
-  a.rec = P->rec; a.rec64 = P->rec64; a.ranges = P->ranges; a.n_lines = P->n_lines;
+  a.rec = P->rec; a.rec64 = P->rec64; a.ranges = P->ranges; a.smally = P->smally; a.n_lines = P->n_lines;
   a.n_tiles = n_tiles; a.tiles_per_xcd = (n_tiles + 7) / 8;
   a.g = to_dev(grid);
   a.out32 = out_f32; a.out64 = out_f64; a.ld = ld; a.inv_scale = 1.0 / P->scale;
-  hipLaunchKernelGGL(voigt_sum_kernel<RTX_VOIGT_P>, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((voigt_sum_kernel<RTX_VOIGT_P, false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  RTX_LAUNCH_CHECK();
+  // fp64 Weideman pass for Doppler-dominated lines; every workgroup returns at once when the layer has none
+  hipLaunchKernelGGL((voigt_sum_kernel<RTX_VOIGT_P, true>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }

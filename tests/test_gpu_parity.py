@@ -294,7 +294,7 @@ def test_full_c3_width_properties():
     assert 0.0 <= float(tau.min()) and float(tau.max()) <= 1.0
     Bmax = float(ref.planckian(np.linspace(500.0, 6000.0, 5501), a["Ts"].max()).max())
     for v in (Lu[0], Ld):
-        assert bool(torch.isfinite(v).all()) and float(v.min()) >= 0.0 and float(v.max()) <= Bmax * (1 + 1e-6)
+        assert bool(torch.isfinite(v).all()) and float(v.min()) >= 0.0 and float(v.max()) <= Bmax * (1 + 1e-5)
     # (1) on a shard, which also checks (2)
     sh = grid.shard(2750000 - 1000, 40000 + 7)
     OD1 = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
