@@ -160,8 +160,8 @@ def main():
     if rank == 0:
         pts = float(N_WAVENUMBERS) * N_LAYERS
         # algorithmic bytes of one voigt_sum_kernel launch (SURVEY 8d stage A): 4 B OD write per point
-        # + one 32 B fp32 line record per (line, layer)
-        alg_bytes = 4.0 * n_loc * N_LAYERS + 32.0 * lines.n * N_LAYERS
+        # + one 48 B fp32 line record per (line, layer)
+        alg_bytes = 4.0 * n_loc * N_LAYERS + 48.0 * lines.n * N_LAYERS
         achieved = alg_bytes / (ms_voigt * 1e-3) / 1e9
         name = ""
         try:

@@ -24,26 +24,42 @@
 #include "w24_coeffs.inc"
 #define INV_SQRT_PI 0.56418958354775628
 
-// Re w(x+iy) by Weideman's rational expansion (misc/hapi.py:9812-9827), real arithmetic.
+// Re w(x+iy) by Weideman's rational expansion (misc/hapi.py:9812-9827), real arithmetic:
+//   Z = (L + i z)/(L - i z),  w = 2 p(Z)/(L - i z)^2 + (1/sqrt(pi))/(L - i z),  p = 24-term polynomial.
+// p is evaluated as pe(Z^2) + Z*po(Z^2): two independent 12-step Horner chains instead of one 24-step
+// chain, so a single wave keeps 4 FMAs in flight (the serial chain stalled the band rows).
 template <typename F>
-__device__ __forceinline__ F weideman_re(F x, F y, const F* __restrict__ coef) {
+__device__ __forceinline__ F weideman_re(F x, F y) {
   const F L = (F)W24_L;
-  // d = L - i z = (L+y) - i x ;  n = L + i z = (L-y) + i x ;  Z = n/d
-  const F dr = L + y, di = -x;
-  const F nr = L - y, ni = x;
-  const F inv = (F)1 / fma(dr, dr, di * di);
-  const F Zr = fma(nr, dr, ni * di) * inv;
-  const F Zi = fma(ni, dr, -(nr * di)) * inv;
-  F pr = coef[0], pi = (F)0;
-#pragma unroll
-  for (int k = 1; k < 24; ++k) {  // Horner in Z, 4 FMA per step
-    const F tr = fma(pr, Zr, fma(-pi, Zi, coef[k]));
-    const F ti = fma(pr, Zi, pi * Zr);
-    pr = tr;
-    pi = ti;
+  constexpr const F* coef = []() constexpr -> const F* { if constexpr (sizeof(F) == 4) return (const F*)W24F; else return (const F*)W24D; }();
+  // d = L - i z = (L+y) - i x ;  n = L + i z = (L-y) + i x ;  Z = n/d = n*conj(d)/|d|^2
+  const F dr = L + y, nr = L - y;
+  const F dd = fma(dr, dr, x * x);
+  F inv;
+  if constexpr (sizeof(F) == 4) {
+    inv = __builtin_amdgcn_rcpf(dd);
+    inv = fma(fma(-dd, inv, (F)1), inv, inv);  // one Newton step: < 1 ulp
+  } else {
+    inv = (F)1 / dd;
   }
-  // 1/d = conj(d)*inv ; w = 2 p /d^2 + (1/sqrt(pi))/d
-  const F ir = dr * inv, ii = -di * inv;
+  const F Zr = fma(nr, dr, -(x * x)) * inv;   // Re[(nr + i x)(dr + i x)]
+  const F Zi = (x * (nr + dr)) * inv;         // Im[...] = x*dr + nr*x
+  const F Wr = fma(Zr, Zr, -(Zi * Zi)), Wi = (F)2 * Zr * Zi;  // W = Z^2
+  // coef[] is in polyval order: p = sum_k coef[k] Z^(23-k); odd powers <-> even k
+  F or_ = coef[0], oi = (F)0;  // po: coefficients of Z^23, Z^21, ... (k = 0, 2, ...)
+  F er = coef[1], ei = (F)0;   // pe: coefficients of Z^22, Z^20, ... (k = 1, 3, ...)
+#pragma unroll
+  for (int k = 2; k < 24; k += 2) {
+    const F t0 = fma(or_, Wr, fma(-oi, Wi, coef[k]));
+    const F t1 = fma(or_, Wi, oi * Wr);
+    const F t2 = fma(er, Wr, fma(-ei, Wi, coef[k + 1]));
+    const F t3 = fma(er, Wi, ei * Wr);
+    or_ = t0; oi = t1; er = t2; ei = t3;
+  }
+  const F pr = fma(or_, Zr, fma(-oi, Zi, er));  // p = pe + Z*po
+  const F pi = fma(or_, Zi, fma(oi, Zr, ei));
+  // 1/d = conj(d)*inv = (dr + i x)*inv ; w = 2 p /d^2 + (1/sqrt(pi))/d
+  const F ir = dr * inv, ii = x * inv;
   const F i2r = fma(ir, ir, -(ii * ii)), i2i = (F)2 * ir * ii;
   return fma((F)2, fma(pr, i2r, -(pi * i2i)), (F)INV_SQRT_PI * ir);
 }
@@ -254,16 +270,17 @@ __global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
               const bool wz64 = fabs(x64) + Q.y < 15.0;
               wz = (CORE64 || near) ? wz64 : wz;
               if (CORE64 && wz) {
-                num = (float)(Q.A * weideman_re<double>(x64, Q.y, W24D));
+                num = (float)(Q.A * weideman_re<double>(x64, Q.y));
                 rden = 1.0f;
               }
             }
-            if (!CORE64 && wz) {
-              num = q.A * weideman_re<float>(x_, q.y, W24F);
+            if (!CORE64 && wz && RTX_ABLATE != 4) {
+              num = q.A * weideman_re<float>(x_, q.y);
               rden = 1.0f;
             }
             num = (u >= ulo && u < uhi && fabsf(u) <= zw_f) ? num : 0.f;
             if (CORE64) touched = true;
+            if (RTX_ABLATE == 5) { acc[0] = fmaf(num, rden, acc[0]); continue; }
 #pragma unroll
             for (int rr = 0; rr < P; ++rr) acc[rr] = (rr == r) ? fmaf(num, rden, acc[rr]) : acc[rr];
           }
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
 }
 
 #ifndef RTX_VOIGT_P
-#define RTX_VOIGT_P 8
+#define RTX_VOIGT_P 4  // measured on MI355X, C3 workload: P=2 12.3 ms, P=4 6.6 ms, P=8 7.3 ms, P=16 14 ms
 #endif
 
 extern "C" int rtx_voigt_tile_points(void) { return 4 * 64 * RTX_VOIGT_P; }
