@@ -97,7 +97,7 @@ def main():
     qratio, mass = engine.species_factors(lines.species, T)
     dev = torch.device("cuda", local)
     OD = torch.empty((N_LAYERS, n_loc), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, 3, per), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * 3 * per,), dtype=torch.float32, device=dev) if world > 1 else None
     packed = torch.zeros((3, per), dtype=torch.float32, device=dev) if world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t_voigt, t_tud = [], []
@@ -113,7 +113,7 @@ def main():
             ev[2].record()
         if world > 1:
             packed[0, :n_loc], packed[1, :n_loc], packed[2, :n_loc] = tau[0], Lu[0], Ld
-            dist.all_gather_into_tensor(gathered, packed)
+            dist.all_gather_into_tensor(gathered, packed.view(-1))
         return tau, Lu, Ld
 
     def sync():

@@ -136,6 +136,23 @@ def main():
             g5.update(w1_tau_alt=tau2, w1_Lu_alt=Lu2, w1_Ld_alt=Ld2, w1_tau_rod=tau3, w1_Lu_rod=Lu3, w1_Ld_rod=Ld3)
     save("g5_tud_windows.npz", seed=synthetic.SEED_C3, n_lines=100000, nu_lo=475.0, nu_hi=6025.0, pad=12.0, **g5)
 
+    # ---- G8 optically THIN atmosphere (the SURVEY 8d table is nearly opaque everywhere: tau ~ 0). Mixing
+    # ratios scaled by 1e-3 put layer optical depths in 1e-3..10, so tau spans (0,1) and L-up/L-down weigh
+    # many layers; all 66 layers of the standard atmosphere (Doppler-dominated upper layers, y << 1).
+    g8 = {}
+    for tag, (xlo, xhi, nlay, scale) in {"a": (1000.0, 1002.0, 32, 1e-3), "b": (2380.0, 2381.0, 66, 3e-4)}.items():
+        sub = synthetic.subset_table(full, xlo - 12.0, xhi + 12.0)
+        name = "g8" + tag
+        inject_table(hapi, name, sub)
+        rt.compute_OD = make_oracle_OD(hapi, name, sub)
+        A = atm[:nlay]
+        opts = dict(DVOUT=0.001, Zs=A[:, 1], Ts=A[:, 5], Ps=A[:, 4], PLs=A[:, 3], MFs_VAL=A[:, 6:8] * 1e6 * scale,
+                    MFs_ID=np.array([1, 2]), theta_r=0.3, N_angle=30, Altitudes=np.asarray([500]), save=False, returnOD=False)
+        Xw, tau, Lu, Ld = quiet(rt.compute_TUD, xlo, xhi, **opts)
+        g8.update({f"{tag}_lo": xlo, f"{tag}_hi": xhi, f"{tag}_nlay": nlay, f"{tag}_scale": scale, f"{tag}_tau": tau,
+                   f"{tag}_Lu": Lu, f"{tag}_Ld": Ld})
+    save("g8_tud_thin.npz", seed=synthetic.SEED_C3, n_lines=100000, nu_lo=475.0, nu_hi=6025.0, pad=12.0, theta_r=0.3, **g8)
+
     # ---- G6 apparent radiance --------------------------------------------------------------
     rng = np.random.default_rng(7)
     nX, nE, nA = 128, 9, 3

@@ -1,0 +1,87 @@
+"""Wavenumber sharding across the GPUs of one node: one process per GPU (torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests), ONE collective per spectrum.
+
+Every stage of the hot path is pointwise in wavenumber except the line windows, so the monochromatic
+grid splits into contiguous chunks with no halo of *data*: each rank keeps only the lines whose wings
+can reach its chunk (engine.max_wing_cm) and evaluates grid values bit-identical to the full grid
+(rtx_grid carries the global offset). The only exchange is the final all-gather of the packed
+[tau, L-up, L-down] chunk (3 x nX/G floats per rank: 8.25 MB at G = 8 on the C3 grid).
+
+The reference has no multi-GPU code; its only parallel axis is multiprocessing.Pool over atmospheres
+(Generate_LWIR_TUD.py:117-150), which maps to independent replicas and needs no code here.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_total, world, rank):
+    """Contiguous equal chunks of ceil(n_total/world) points (the last rank may be short or empty)."""
+    per = (int(n_total) + world - 1) // world
+    off = min(rank * per, int(n_total))
+    return off, max(0, min(per, int(n_total) - off)), per
+
+
+def subset_lines(columns, x_lo, x_hi, reach):
+    """Rows of a line table (column dict) whose centre lies within `reach` cm^-1 of [x_lo, x_hi]."""
+    nu = np.asarray(columns["nu"])
+    m = (nu >= x_lo - reach) & (nu <= x_hi + reach)
+    return {k: np.asarray(v)[m] for k, v in columns.items()}
+
+
+def all_gather_spectra(local, n_total, group=None):
+    """local: [C][n_loc] tensor (C stacked spectra of this rank's chunk, any device the backend supports).
+    Returns [C][n_total] on every rank. One all_gather_into_tensor of a padded [C][per] block."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local[:, :n_total]
+    rank = dist.get_rank(group)
+    off, n_loc, per = shard_bounds(n_total, world, rank)
+    assert local.shape[1] == n_loc, (local.shape, n_loc)
+    C = local.shape[0]
+    send = local if n_loc == per else torch.nn.functional.pad(local, (0, per - n_loc))
+    send = send.contiguous().view(-1)  # flat buffers: accepted by both the RCCL and the gloo backends
+    recv = torch.empty((world * C * per,), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv.view(world, C, per).permute(1, 0, 2).reshape(C, world * per)[:, :n_total]
+
+
+def sharded_tud(compute_local, columns, Xmin, Xmax, n_total, reach, group=None):
+    """Run `compute_local(sub_table, offset, n_loc) -> [3][n_loc] tensor (tau, Lu, Ld)` on this rank's
+    chunk of np.linspace(Xmin, Xmax, n_total) and reassemble the full spectra on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    off, n_loc, _ = shard_bounds(n_total, world, rank)
+    step = (Xmax - Xmin) / (n_total - 1)
+    x_lo, x_hi = Xmin + off * step, Xmin + (off + max(n_loc, 1) - 1) * step
+    sub = subset_lines(columns, x_lo, x_hi, reach)
+    local = compute_local(sub, off, n_loc)
+    return all_gather_spectra(local, n_total, group)
+
+
+def compute_TUD_sharded(Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, PLs, MFs_VAL, MFs_ID, Altitudes=(500,), theta_r=0.0,
+                        N_angle=30, group=None):
+    """compute_TUD (radiative_transfer.py:274-392) with the spectral axis sharded over the ranks of
+    `group`; every rank returns the full (X, tau, Lu, Ld) as float32 device tensors (X as NumPy fp64).
+    One sensor altitude / slant path per call."""
+    from . import engine
+    n_total = int(np.ceil((Xmax - Xmin) / DVOUT))
+    grid_full = engine.Grid(Xmin, Xmax, n_total)
+    reach = engine.max_wing_cm(line_table, Ts, np.asarray(Ps, dtype=np.float64) / 101325.0) + grid_full.step
+
+    def compute_local(sub, off, n_loc):
+        dev = engine.device()
+        if n_loc == 0:
+            return torch.empty((3, 0), dtype=torch.float32, device=dev)
+        grid = grid_full.shard(off, n_loc)
+        lines = engine.LineTable(sub)
+        try:
+            OD = engine.optical_depths(lines, grid, Ts, Ps, PLs, MFs_VAL, MFs_ID)
+            tau, Lu, Ld, _ = engine.tud(OD, grid, Ts, Zs, Altitudes=Altitudes, theta_r=theta_r, N_angle=N_angle)
+            return torch.stack([tau[0], Lu[0], Ld])
+        finally:
+            torch.cuda.synchronize()
+            lines.close()
+
+    full = sharded_tud(compute_local, line_table, Xmin, Xmax, n_total, reach, group)
+    return np.linspace(Xmin, Xmax, n_total), full[0], full[1], full[2]

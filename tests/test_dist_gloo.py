@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the N>1 path of radtxfr_amd.dist -- contiguous wavenumber shards, each rank
+keeping only the lines that can reach its shard, ONE all-gather to reassemble (tau, Lu, Ld).
+The per-rank compute is stood in for by the oracle (no GPU here); the sharding, the line subsetting
+(engine.max_wing_cm) and the reassembly are the code under test."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cpu_ref as ref
+from radtxfr_amd import dist as rdist
+from radtxfr_amd import engine, synthetic
+
+LO, HI, N = 1000.0, 1003.0, 3001  # odd on purpose: ragged last shard
+
+
+def _case():
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    sub = synthetic.subset_table(full, LO - 15.0, HI + 15.0)
+    a = synthetic.c3_atmosphere(8)
+    a["MFs_VAL"] = a["MFs_VAL"] * 1e-3  # optically thin enough that tau is not ~0 everywhere
+    return sub, a
+
+
+def _oracle(table, X, a):
+    OD = np.stack([ref.layer_od(table, X, a["Ts"][k], a["Ps"][k], a["PLs"][k], a["MFs_VAL"][k], a["MFs_ID"])
+                   for k in range(a["Ts"].size)], axis=1)
+    return ref.tud_from_od(X, OD, a["Ts"], a["Zs"])
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        table, a = _case()
+        X = np.linspace(LO, HI, N)
+        reach = engine.max_wing_cm(table, a["Ts"], a["Ps"] / 101325.0) + (HI - LO) / (N - 1)
+        seen = {}
+
+        def compute_local(sub, off, n_loc):
+            seen["n_lines"] = sub["nu"].size
+            tau, Lu, Ld = _oracle(sub, X[off:off + n_loc], a)
+            return torch.from_numpy(np.stack([tau, Lu, Ld]))
+
+        full = rdist.sharded_tud(compute_local, table, LO, HI, N, reach)
+        np.save(os.path.join(out_dir, f"r{rank}.npy"), full.numpy())
+        np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array([seen["n_lines"], table["nu"].size]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_bounds():
+    for n, w in ((5500000, 8), (3001, 2), (7, 4), (3, 8)):
+        got = [rdist.shard_bounds(n, w, r) for r in range(w)]
+        assert sum(g[1] for g in got) == n
+        assert all(got[r][0] == sum(g[1] for g in got[:r]) or got[r][1] == 0 for r in range(w))
+
+
+def test_world2_gloo_sharded_tud(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    table, a = _case()
+    X = np.linspace(LO, HI, N)
+    want = np.stack(_oracle(table, X, a))
+    assert want[0].min() < 0.9 and want[0].max() > 0.1  # the case exercises real transmittances
+    for r in range(world):
+        got = np.load(tmp_path / f"r{r}.npy")
+        assert got.shape == (3, N)
+        # shards see fewer lines than the full table, yet nothing that reaches them is dropped
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+        nl = np.load(tmp_path / f"n{r}.npy")
+        assert nl[0] < nl[1]
+
+
+def test_all_gather_single_process_identity():
+    x = torch.arange(12.0).reshape(3, 4)
+    assert torch.equal(rdist.all_gather_spectra(x, 4), x)

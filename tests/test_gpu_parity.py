@@ -187,6 +187,24 @@ def test_g5_compute_tud_quirks_golden(rt, golden):
     assert rel_err(Ld, g["w1_Ld_rod"]) <= TOL_L
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g8_compute_tud_thin_golden(rt, golden, tag):
+    """Optically thin cases (tau spans (0,1); 66 layers with Doppler-dominated lines in case b): the
+    SURVEY 8d table itself is nearly opaque, which would leave tau and the layer weighting untested."""
+    g = golden("g8_tud_thin.npz")
+    full = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    lo, hi, nl = float(g[tag + "_lo"]), float(g[tag + "_hi"]), int(g[tag + "_nlay"])
+    sub = synthetic.subset_table(full, lo - float(g["pad"]), hi + float(g["pad"]))
+    a = synthetic.load_standard_atmosphere()[:nl]
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, Zs=a[:, 1], Ts=a[:, 5], Ps=a[:, 4], PLs=a[:, 3],
+                                    MFs_VAL=a[:, 6:8] * 1e6 * float(g[tag + "_scale"]), MFs_ID=np.array([1, 2]),
+                                    theta_r=float(g["theta_r"]), Altitudes=np.asarray([500]))
+    assert g[tag + "_tau"].max() - g[tag + "_tau"].min() > 0.3
+    assert np.max(np.abs(tau - g[tag + "_tau"])) <= TOL_TAU
+    assert rel_err(Lu, g[tag + "_Lu"]) <= TOL_L
+    assert rel_err(Ld, g[tag + "_Ld"]) <= TOL_L
+
+
 def test_compute_tud_options_do_not_leak(rt, golden):
     """Divergence from quirk 2, on purpose: kwargs must not persist in the module-level options."""
     before = rt.options["DVOUT"]

@@ -103,6 +103,21 @@ def test_g5_tud_windows(golden):
             close(d3, g["w1_Ld_rod"], rtol=1e-11)
 
 
+def test_g8_tud_thin(golden):
+    g = golden("g8_tud_thin.npz")
+    full = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    A = synthetic.load_standard_atmosphere()
+    for tag in "ab":
+        lo, hi, nl = float(g[tag + "_lo"]), float(g[tag + "_hi"]), int(g[tag + "_nlay"])
+        sub = synthetic.subset_table(full, lo - float(g["pad"]), hi + float(g["pad"]))
+        a = A[:nl]
+        X, tau, Lu, Ld = ref.compute_TUD(sub, lo, hi, 0.001, a[:, 1], a[:, 5], a[:, 4], a[:, 3], a[:, 6:8] * 1e6 * float(g[tag + "_scale"]),
+                                         np.array([1, 2]), theta_r=float(g["theta_r"]))
+        close(tau, g[tag + "_tau"], rtol=1e-11)
+        close(Lu, g[tag + "_Lu"], rtol=1e-11)
+        close(Ld, g[tag + "_Ld"], rtol=1e-11)
+
+
 def test_g6_apparent_radiance(golden):
     g = golden("g6_apparent_radiance.npz")
     L0 = ref.compute_LWIR_apparent_radiance(g["X"], g["emis"], g["Ts"], g["tau"], g["La"], g["Ld"])
