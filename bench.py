@@ -163,6 +163,15 @@ def main():
         # + one 48 B fp32 line record per (line, layer)
         alg_bytes = 4.0 * n_loc * N_LAYERS + 48.0 * lines.n * N_LAYERS
         achieved = alg_bytes / (ms_voigt * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters: cannot be collected inside this process (rocprofv3
+        # passes), so the committed round-N measurement of this exact workload is reported, else null
+        traffic = None
+        if world == 1:
+            cand = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm_traffic.json")) \
+                if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+            if cand:
+                with open(os.path.join(ROOT, "profiles", cand[-1])) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
         name = ""
         try:
             buf = C.create_string_buffer(128)
@@ -182,7 +191,8 @@ def main():
                        "line_table": "synthetic HITRAN-format H2O+CO2, seed 20261005",
                        "parallelism": f"wavenumber-sharded x{world}" + (" + 1 RCCL all-gather" if world > 1 else "")},
             "roofline": {"kernel": "voigt_sum_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (cand[-1] if traffic is not None else None),
                          "ms_per_launch": ms_voigt, "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "VALU/transcendental-bound by construction (SURVEY 8d): ~10 fp32 ops + 1 rcp per "
                                  "line-point evaluation; see DESIGN.md for the VALU roofline",
