@@ -127,12 +127,15 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
 //                 Keeping that code out of the main kernel keeps it at ~64 VGPRs (the fp64 Horner
 //                 chain costs 140 and drops the occupancy of the whole line loop to 3 waves/SIMD).
 template <int P, bool CORE64>
-__global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
+#ifndef RTX_VOIGT_WAVES
+#define RTX_VOIGT_WAVES 1  /* min waves per SIMD asked of the register allocator */
+#endif
+__global__ __launch_bounds__(256, RTX_VOIGT_WAVES) void voigt_sum_kernel(VsArgs a) {
   constexpr int WPTS = 64 * P;    // points per wave
   constexpr int TILE = 4 * WPTS;  // points per workgroup
   constexpr int CHUNK = 256;      // candidates staged per round (one per thread)
   __shared__ LineRec s_rec[CHUNK];
-  __shared__ int s_list[4][CHUNK + 2];  // per consuming wave: (class << 8 | slot), order-preserving; +2 prefetch slack
+  __shared__ int s_list[4][CHUNK + 4];  // per consuming wave: (class << 8 | slot), order-preserving; +4 prefetch slack
   __shared__ int s_cnt[4][4];           // [staging wave][consuming wave]
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
@@ -201,23 +204,14 @@ __global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
 
     // ---- this wave's lines, in table order (LDS broadcast reads, software-prefetched) ----------
     const int* __restrict__ list = s_list[wave];
-    int e_nxt = list[0];
-    LineRec q_nxt = s_rec[e_nxt & 255];
-    e_nxt = __builtin_amdgcn_readfirstlane(e_nxt);
-    int e_nn = list[1];
-    for (int j = 0; j < total; ++j) {
-      const LineRec q = q_nxt;
-      const int e = e_nxt;
-      e_nxt = __builtin_amdgcn_readfirstlane(e_nn);
-      q_nxt = s_rec[e_nxt & 255];  // garbage past the end of the list: never used
-      e_nn = list[j + 2];
+    auto visit = [&](const LineRec& q, const int e) __attribute__((always_inline)) {
       // u = i - i0 as a float: integer-valued and exact while |i - i0| < 2^24 (any sane window);
       // |i0| is clamped by the prologue, so wa - i0 cannot overflow int32
       const float u0 = (float)(wa - __builtin_amdgcn_readfirstlane(q.i0)) + lanef;
 #ifndef RTX_ABLATE
 #define RTX_ABLATE 0  /* timing experiments only: 1 = no phase B, 2 = every visit takes the fast path, 3 = no math */
 #endif
-      if (RTX_ABLATE == 3) continue;
+      if (RTX_ABLATE == 3) return;
       if (!CORE64 && ((e >> 8) == 1 || RTX_ABLATE == 2)) {
 #pragma unroll
         for (int r = 0; r < P; ++r) {
@@ -233,13 +227,19 @@ __global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
         const float zw_f = qzw > 0 ? (float)qzw : -1.0f;  // |u| <= zw  <=>  inside the band
         const int rb = qlo > wa ? (qlo - wa) >> 6 : 0;
         const int re = ((qhi - 1 - wa) >> 6) + 1 < P ? ((qhi - 1 - wa) >> 6) + 1 : P;
+        // rows [c0,c1) lie wholly inside the window; rows [z0,z1] touch the band: the others need no mask
+        const int c0 = qlo > wa ? (qlo - wa + 63) >> 6 : 0;
+        const int c1 = (qhi - wa) >> 6;
+        const int z0 = qzw > 0 ? ((qi0 - qzw - wa) >> 6) : P;
+        const int z1 = qzw > 0 ? ((qi0 + qzw - wa) >> 6) : -1;
 #pragma unroll
         for (int r = 0; r < P; ++r) {
           if (CORE64 || r < rb) continue;
           if (r >= re) break;
           const float u = u0 + (float)(64 * r);
           RTX_FARWING(u, q, num, rden);
-          num = (u >= ulo && u < uhi && !(fabsf(u) <= zw_f)) ? num : 0.f;
+          if (r < c0 || r >= c1 || (r >= z0 && r <= z1))
+            num = (u >= ulo && u < uhi && !(fabsf(u) <= zw_f)) ? num : 0.f;
           acc[r] = fmaf(num, rden, acc[r]);
         }
         // Phase B: the few rows around the line centre that hold band points. A line with y < 1 is
@@ -286,7 +286,21 @@ __global__ __launch_bounds__(256) void voigt_sum_kernel(VsArgs a) {
           }
         }
       }
+    };
+    // two records in flight, no register copies: while one line is evaluated the next one's LDS reads land
+    int e0 = __builtin_amdgcn_readfirstlane(list[0]), e1 = __builtin_amdgcn_readfirstlane(list[1]);
+    LineRec qa = s_rec[e0 & 255], qb = s_rec[e1 & 255];  // garbage slots past the list end are never visited
+    int j = 0;
+    for (; j + 1 < total; j += 2) {
+      const int ea = e0, eb = e1;
+      e0 = __builtin_amdgcn_readfirstlane(list[j + 2]);
+      e1 = __builtin_amdgcn_readfirstlane(list[j + 3]);
+      visit(qa, ea);
+      qa = s_rec[e0 & 255];
+      visit(qb, eb);
+      qb = s_rec[e1 & 255];
     }
+    if (j < total) visit(qa, e0);
     __syncthreads();
   }
 
