@@ -150,6 +150,15 @@ int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t nx, const f
             int64_t nS, int64_t ldY, int nB, const double* centre, const double* sigma,
             float* Y_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Knot spectra -> monochromatic axis, column-wise np.interp. The reference's emissivity databases
+ * live on ~1 cm^-1 knots (Generate_ASTER_emissivity_DB.py:48-52,81) and are resampled with
+ * np.interp / interp1d before compute_LWIR_apparent_radiance (LWIR_HSI_Generator.py:151-167).
+ *   Xk[nk] fp64 ascending knots; F[nk][nS] float32; out[nx][nS] float32; X == NULL -> grid.
+ *   Outside [Xk[0], Xk[nk-1]] the end values are held, like np.interp. */
+int rtx_interp_knots(const rtx_grid* grid, const double* X, int64_t nx, const double* Xk,
+                     int64_t nk, const float* F, int64_t nS, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

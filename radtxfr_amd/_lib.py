@@ -39,6 +39,7 @@ PROTOTYPES = {
     "rtx_tud": (_i32, [_vp, _i64, _gp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "rtx_apparent_radiance": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rtx_ils": (_i32, [_i32, _gp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "rtx_interp_knots": (_i32, [_gp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -1,6 +1,7 @@
 // Internal definitions shared by the HIP translation units of libradtxfr_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -42,6 +43,19 @@ int rtx_check_grid(const rtx_grid* g);
 __device__ __forceinline__ double grid_x(const GridDev& g, long long ig) {
   double v = __dadd_rn(__dmul_rn((double)ig, g.step), g.xmin);
   return (ig == g.n_total - 1) ? g.xmax : v;
+}
+
+// ---- Planck radiance in fp32 from an fp64 exponent (shared by the TUD and at-sensor kernels) ----------
+// B(nu,T) in uW/(cm^2 sr cm^-1):  c1*(100 nu)^3*1e4 / (exp(c2*100 nu/T) - 1)
+__device__ __forceinline__ float planck_f32(double c1x3, double x, double c2l2e_over_T) {
+  const double t = x * c2l2e_over_T;  // log2 of the exponential, fp64
+  if (t < 1.5) {                      // small arguments (far-IR / microwave): expm1 in fp64
+    return (float)(c1x3 / expm1(t * 0.6931471805599453));
+  }
+  const double n = rint(t);
+  const float f = (float)(t - n);     // |f| <= 1/2, exact difference
+  const float e = ldexpf(__builtin_amdgcn_exp2f(f), (int)n);  // inf above 2^128: B -> 0, as it should
+  return (float)c1x3 * __builtin_amdgcn_rcpf(e - 1.0f);
 }
 
 // ---- per-(line,layer) records written by the prologue, read by the line-sum --------------------

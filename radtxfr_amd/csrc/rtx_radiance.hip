@@ -26,13 +26,20 @@ struct RadArgs {
   float* Ls;
 };
 
-__global__ __launch_bounds__(256) void apparent_radiance_kernel(RadArgs a) {
+// General case (several atmospheres and/or a dT axis). Grid = (spectral channel, emissivity chunk).
+// Threads form a TA x TE tile: ta walks the [nA][nT] slab of one emissivity (fastest output axis, so
+// stores coalesce), te walks emissivities; no integer division in the streaming loop.
+__global__ __launch_bounds__(256) void apparent_radiance_kernel(RadArgs a, int log2TA, long long e_chunk) {
   extern __shared__ float s_mem[];
   const long long nAT = a.nA * a.nT;
   float* s_B = s_mem;             // [nA*nT]
   float* s_tau = s_B + nAT;       // [nA]
   float* s_La = s_tau + a.nA;
   float* s_Ld = s_La + a.nA;
+  const int TA = 1 << log2TA, TE = 256 >> log2TA;
+  const int ta = threadIdx.x & (TA - 1), te = threadIdx.x >> log2TA;
+  const long long e_lo = (long long)blockIdx.y * e_chunk;
+  const long long e_hi = e_lo + e_chunk < a.nE ? e_lo + e_chunk : a.nE;
   for (long long ix = blockIdx.x; ix < a.nX; ix += gridDim.x) {
     __syncthreads();
     const double x100 = a.X[ix] * 100.0;
@@ -48,17 +55,51 @@ __global__ __launch_bounds__(256) void apparent_radiance_kernel(RadArgs a) {
       s_Ld[ia] = a.Ld[ix * a.nA + ia];
     }
     __syncthreads();
-    const long long slab = a.nE * nAT;
     const float* em = a.emis + ix * a.nE;
-    float* L = a.L + ix * slab;
-    float* Ls = a.Ls ? a.Ls + ix * slab : nullptr;
-    for (long long o = threadIdx.x; o < slab; o += blockDim.x) {
-      const long long ie = o / nAT, r = o - ie * nAT;
-      const long long ia = r / a.nT;
+    float* L = a.L + ix * a.nE * nAT;
+    float* Ls = a.Ls ? a.Ls + ix * a.nE * nAT : nullptr;
+    for (long long ie = e_lo + te; ie < e_hi; ie += TE) {
       const float e = em[ie];
-      const float ls = e * s_B[r] + (1.0f - e) * s_Ld[ia];  // (:1064)
-      L[o] = s_tau[ia] * ls + s_La[ia];                      // (:1065)
-      if (Ls) Ls[o] = ls;
+      long long ia = ta / a.nT;  // once per emissivity, then advanced incrementally
+      long long it = ta - ia * a.nT;
+      for (long long r = ta; r < nAT; r += TA) {
+        const float ls = e * s_B[r] + (1.0f - e) * s_Ld[ia];  // (:1064)
+        const long long o = ie * nAT + r;
+        L[o] = s_tau[ia] * ls + s_La[ia];                      // (:1065)
+        if (Ls) Ls[o] = ls;
+        it += TA;
+        while (it >= a.nT) { it -= a.nT; ++ia; }
+      }
+    }
+  }
+}
+
+// One atmosphere, no dT axis (config C4): pure streaming, one spectral channel per workgroup-iteration,
+// 16-B loads/stores along the emissivity axis, Planck per thread in fp32 from an fp64 exponent.
+__global__ __launch_bounds__(256) void apparent_radiance_row_kernel(RadArgs a) {
+  const long long nE4 = a.nE >> 2;
+  for (long long ix = blockIdx.x; ix < a.nX; ix += gridDim.x) {
+    const double x = a.X[ix];
+    const double x100 = x * 100.0;
+    const float B = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, 100.0 * RT_C2 * 1.4426950408889634 / a.Ts[0]);
+    const float tau = a.tau[ix], La = a.La[ix], Ld = a.Ld[ix];
+    const float4* em = reinterpret_cast<const float4*>(a.emis + ix * a.nE);
+    float4* L = reinterpret_cast<float4*>(a.L + ix * a.nE);
+    float4* Ls = a.Ls ? reinterpret_cast<float4*>(a.Ls + ix * a.nE) : nullptr;
+    for (long long q = threadIdx.x; q < nE4; q += blockDim.x) {
+      const float4 e = em[q];
+      float4 ls, l;
+      ls.x = e.x * B + (1.0f - e.x) * Ld; ls.y = e.y * B + (1.0f - e.y) * Ld;
+      ls.z = e.z * B + (1.0f - e.z) * Ld; ls.w = e.w * B + (1.0f - e.w) * Ld;
+      l.x = tau * ls.x + La; l.y = tau * ls.y + La; l.z = tau * ls.z + La; l.w = tau * ls.w + La;
+      L[q] = l;
+      if (Ls) Ls[q] = ls;
+    }
+    for (long long ie = (nE4 << 2) + threadIdx.x; ie < a.nE; ie += blockDim.x) {  // ragged tail
+      const float e = a.emis[ix * a.nE + ie];
+      const float ls = e * B + (1.0f - e) * Ld;
+      a.L[ix * a.nE + ie] = tau * ls + La;
+      if (a.Ls) a.Ls[ix * a.nE + ie] = ls;
     }
   }
 }
@@ -70,15 +111,32 @@ extern "C" int rtx_apparent_radiance(const double* X, int64_t nX, const float* e
   if (dT == nullptr) nT = 1;
   if (nX == 0 || nE == 0 || nA == 0 || nT == 0) return 0;
   if (!X || !emis || !Ts || !tau || !La || !Ld || !L) RTX_FAIL("a required pointer is NULL");
-  const size_t lds = sizeof(float) * (size_t)(nA * nT + 3 * nA);
-  if (lds > 150 * 1024) RTX_FAIL("nA*nT=%lld does not fit the per-channel LDS staging", (long long)(nA * nT));
   RadArgs a;
   a.X = X; a.nX = nX; a.nE = nE; a.nA = nA; a.nT = nT; a.emis = emis; a.Ts = Ts; a.tau = tau; a.La = La; a.Ld = Ld;
   a.dT = dT; a.L = L; a.Ls = Ls;
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned16 = (nE % 4 == 0) && (((uintptr_t)emis | (uintptr_t)L | (uintptr_t)Ls) % 16 == 0);
+  if (nA == 1 && nT == 1 && dT == nullptr && aligned16) {
+    const long long blocks = nX < 256 * 32 ? nX : 256 * 32;
+    hipLaunchKernelGGL(apparent_radiance_row_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    RTX_LAUNCH_CHECK();
+    return 0;
+  }
+  const long long nAT = nA * nT;
+  const size_t lds = sizeof(float) * (size_t)(nAT + 3 * nA);
+  if (lds > 150 * 1024) RTX_FAIL("nA*nT=%lld does not fit the per-channel LDS staging", (long long)nAT);
   if (lds > 64 * 1024)
     RTX_HIP(hipFuncSetAttribute((const void*)apparent_radiance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  long long blocks = nX < 256 * 16 ? nX : 256 * 16;
-  hipLaunchKernelGGL(apparent_radiance_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+  int log2TA = 0;
+  while (log2TA < 8 && (2LL << log2TA) <= nAT) ++log2TA;  // TA = largest power of two <= min(nAT, 256)
+  // enough workgroups to fill 256 CUs even for the reference's 128-channel use: split the emissivity axis
+  long long bx = nX < 4096 ? nX : 4096;
+  long long chunks = (2048 + bx - 1) / bx;
+  if (chunks > nE) chunks = nE;
+  if (chunks < 1) chunks = 1;
+  const long long e_chunk = (nE + chunks - 1) / chunks;
+  chunks = (nE + e_chunk - 1) / e_chunk;
+  hipLaunchKernelGGL(apparent_radiance_kernel, dim3((unsigned)bx, (unsigned)chunks), dim3(256), lds, st, a, log2TA, e_chunk);
   RTX_LAUNCH_CHECK();
   return 0;
 }
@@ -191,6 +249,50 @@ __global__ __launch_bounds__(256) void ils_columns_kernel(IlsArgs a) {
   }
 }
 
+// nS large and a multiple of 4: lanes <-> 4 adjacent spectra (16-B loads, 1 KiB contiguous per wave-instruction
+// and grid row); the 4 waves split the band's grid points. Grid = (band, 256-column block).
+__global__ __launch_bounds__(256) void ils_columns4_kernel(IlsArgs a) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long col4 = (long long)blockIdx.y * 64 + lane;  // index of the float4 column group
+  const long long nS4 = a.nS >> 2, ld4 = a.ldY >> 2;
+  const double c = a.centre[b], s = a.sigma[b];
+  const double R = a.kind == 0 ? s : 14.0 * s;
+  const long long lo = ils_bound(a, c - R, 1), hi = ils_bound(a, c + R, 0);
+  const bool live = col4 < nS4;
+  const float4* Y4 = reinterpret_cast<const float4*>(a.Y) + (live ? col4 : 0);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float wsum = 0.f;
+  long long i = lo + wave;
+  for (; i + 4 < hi; i += 8) {  // two rows in flight per wave
+    const float w0 = ils_weight(a.kind, ils_x(a, i), c, s), w1 = ils_weight(a.kind, ils_x(a, i + 4), c, s);
+    const float4 y0 = Y4[i * ld4], y1 = Y4[(i + 4) * ld4];
+    wsum += w0 + w1;
+    acc.x = fmaf(w0, y0.x, acc.x); acc.y = fmaf(w0, y0.y, acc.y); acc.z = fmaf(w0, y0.z, acc.z); acc.w = fmaf(w0, y0.w, acc.w);
+    acc.x = fmaf(w1, y1.x, acc.x); acc.y = fmaf(w1, y1.y, acc.y); acc.z = fmaf(w1, y1.z, acc.z); acc.w = fmaf(w1, y1.w, acc.w);
+  }
+  for (; i < hi; i += 4) {
+    const float w0 = ils_weight(a.kind, ils_x(a, i), c, s);
+    const float4 y0 = Y4[i * ld4];
+    wsum += w0;
+    acc.x = fmaf(w0, y0.x, acc.x); acc.y = fmaf(w0, y0.y, acc.y); acc.z = fmaf(w0, y0.z, acc.z); acc.w = fmaf(w0, y0.w, acc.w);
+  }
+  __shared__ float4 s_acc[4][64];
+  __shared__ float s_w[4];
+  s_acc[wave][lane] = acc;
+  if (lane == 0) s_w[wave] = wsum;
+  __syncthreads();
+  if (wave == 0 && live) {
+    const float N = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    float4 v;
+    v.x = ((s_acc[0][lane].x + s_acc[1][lane].x) + (s_acc[2][lane].x + s_acc[3][lane].x)) / N;
+    v.y = ((s_acc[0][lane].y + s_acc[1][lane].y) + (s_acc[2][lane].y + s_acc[3][lane].y)) / N;
+    v.z = ((s_acc[0][lane].z + s_acc[1][lane].z) + (s_acc[2][lane].z + s_acc[3][lane].z)) / N;
+    v.w = ((s_acc[0][lane].w + s_acc[1][lane].w) + (s_acc[2][lane].w + s_acc[3][lane].w)) / N;
+    reinterpret_cast<float4*>(a.Yout + (size_t)b * a.nS)[col4] = v;
+  }
+}
+
 extern "C" int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t nx, const float* Y, int64_t nS, int64_t ldY,
                        int nB, const double* centre_d, const double* sigma_d, float* Y_out, void* stream) {
   if (kind != 0 && kind != 1) RTX_FAIL("kind must be 0 (triangle) or 1 (Gaussian)");
@@ -209,7 +311,92 @@ extern "C" int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t 
   hipStream_t st = (hipStream_t)stream;
   if (nS <= 4) hipLaunchKernelGGL(ils_points_kernel<4>, dim3(nB), dim3(256), 0, st, a);
   else if (nS <= 16) hipLaunchKernelGGL(ils_points_kernel<16>, dim3(nB), dim3(256), 0, st, a);
+  else if (nS % 4 == 0 && ldY % 4 == 0 && (((uintptr_t)Y | (uintptr_t)Y_out) % 16 == 0))
+    hipLaunchKernelGGL(ils_columns4_kernel, dim3(nB, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(ils_columns_kernel, dim3(nB, (unsigned)((nS + 63) / 64)), dim3(256), 0, st, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Knot spectra -> monochromatic grid: np.interp(X, Xk, F[:, s]) for every column s (C4/C5 of SURVEY 8d:
+// emissivities live on the ~1 cm^-1 ASTER-DB knots, Generate_ASTER_emissivity_DB.py:48-52,81, and are
+// "linearly interpolated to the hi-res grid"). Lanes <-> columns (coalesced rows of F and of the output),
+// one grid point per workgroup-iteration; the knot interval is found once per point (wave-uniform).
+struct InterpArgs {
+  GridDev g;
+  const double* X;
+  long long nx;
+  const double* Xk;
+  long long nk, nS;
+  const float* F;   // [nk][nS]
+  float* out;       // [nx][nS]
+};
+
+__global__ __launch_bounds__(256) void interp_knots_kernel(InterpArgs a) {
+  constexpr int R = 64;  // grid points per workgroup-iteration: their knot searches run in parallel
+  __shared__ long long s_j[R];
+  __shared__ float s_t[R];
+  const long long n_groups = (a.nx + R - 1) / R;
+  const bool vec = (a.nS % 4 == 0) && ((((uintptr_t)a.F | (uintptr_t)a.out) & 15) == 0);
+  for (long long grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const long long i0 = grp * R;
+    const int rows = (int)(a.nx - i0 < R ? a.nx - i0 : R);
+    __syncthreads();
+    if ((int)threadIdx.x < rows) {
+      const long long i = i0 + threadIdx.x;
+      const double x = a.X ? a.X[i] : grid_x(a.g, a.g.offset + i);
+      // j = last knot with Xk[j] <= x, clamped to [0, nk-2]; outside the knots np.interp holds the end values
+      long long lo = 0, hi = a.nk - 1;
+      while (hi - lo > 1) {
+        const long long mid = (lo + hi) >> 1;
+        if (a.Xk[mid] <= x) lo = mid; else hi = mid;
+      }
+      const double x0 = a.Xk[lo], x1 = a.Xk[lo + 1];
+      double t = (x - x0) / (x1 - x0);
+      t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+      s_j[threadIdx.x] = lo;
+      s_t[threadIdx.x] = (float)t;
+    }
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+      const float tf = s_t[r];
+      const float* f0 = a.F + s_j[r] * a.nS;
+      const float* f1 = f0 + a.nS;
+      float* o = a.out + (i0 + r) * a.nS;
+      if (vec) {
+        const float4 *f04 = reinterpret_cast<const float4*>(f0), *f14 = reinterpret_cast<const float4*>(f1);
+        float4* o4 = reinterpret_cast<float4*>(o);
+        for (long long q = threadIdx.x; q < (a.nS >> 2); q += blockDim.x) {
+          const float4 u = f04[q], v = f14[q];
+          float4 w;
+          w.x = fmaf(tf, v.x - u.x, u.x); w.y = fmaf(tf, v.y - u.y, u.y);
+          w.z = fmaf(tf, v.z - u.z, u.z); w.w = fmaf(tf, v.w - u.w, u.w);
+          o4[q] = w;
+        }
+      } else {
+        for (long long sidx = threadIdx.x; sidx < a.nS; sidx += blockDim.x) o[sidx] = fmaf(tf, f1[sidx] - f0[sidx], f0[sidx]);
+      }
+    }
+  }
+}
+
+extern "C" int rtx_interp_knots(const rtx_grid* grid, const double* X, int64_t nx, const double* Xk, int64_t nk,
+                                const float* F, int64_t nS, float* out, void* stream) {
+  if (!X) {
+    if (rtx_check_grid(grid)) return 1;
+    if (nx != grid->n) RTX_FAIL("nx=%lld != grid->n=%lld", (long long)nx, (long long)grid->n);
+  }
+  if (nk < 2) RTX_FAIL("need at least 2 knots");
+  if (nx < 0 || nS < 0) RTX_FAIL("negative size");
+  if (nx == 0 || nS == 0) return 0;
+  if (!Xk || !F || !out) RTX_FAIL("a required pointer is NULL");
+  InterpArgs a;
+  if (grid) a.g = to_dev(grid); else { a.g.xmin = a.g.xmax = a.g.step = 0; a.g.n_total = a.g.offset = a.g.n = 0; }
+  a.X = X; a.nx = nx; a.Xk = Xk; a.nk = nk; a.nS = nS; a.F = F; a.out = out;
+  const long long groups = (nx + 63) / 64;
+  const long long blocks = groups < 256 * 16 ? groups : 256 * 16;
+  hipLaunchKernelGGL(interp_knots_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }

@@ -99,18 +99,6 @@ struct TudArgs {
   int count[TUD_MAX_ALT];
 };
 
-// B(nu,T) in uW/(cm^2 sr cm^-1):  c1*(100 nu)^3*1e4 / (exp(c2*100 nu/T) - 1)
-__device__ __forceinline__ float planck_f32(double c1x3, double x, double c2l2e_over_T) {
-  const double t = x * c2l2e_over_T;  // log2 of the exponential, fp64
-  if (t < 1.5) {                      // small arguments (far-IR / microwave): expm1 in fp64
-    return (float)(c1x3 / expm1(t * 0.6931471805599453));
-  }
-  const double n = rint(t);
-  const float f = (float)(t - n);     // |f| <= 1/2, exact difference
-  const float e = ldexpf(__builtin_amdgcn_exp2f(f), (int)n);  // inf above 2^128: B -> 0, as it should
-  return (float)c1x3 * __builtin_amdgcn_rcpf(e - 1.0f);
-}
-
 template <int NL>
 __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,56 @@
+"""At-sensor band radiances on device tensors: the C4 pipeline of SURVEY.md 8d
+(emissivity knots -> monochromatic grid -> compute_LWIR_apparent_radiance -> ILS_MAKO) without ever
+leaving the GPU. The reference runs these steps as separate scripts on band-averaged TUDs
+(Compute_LWIR_Apparent_Radiance.py:25 on the output of Generate_LWIR_TUD_MAKO.py:34-36) because its
+ILS needs an (nS,nX,nB) temporary (1.4 TB at 2000 spectra); here the monochromatic arrays fit in HBM
+(560 k wavenumbers x 2000 spectra x 4 B = 4.5 GB) and the order "radiance first, ILS second" is exact.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, engine
+from .radiative_transfer import _MAKO_UM
+
+
+def interp_knots(grid, Xk, F):
+    """np.interp(grid, Xk, F[:, s]) for every column: F [nk][nS] float32 device -> [grid.n][nS] float32."""
+    lib = _lib.load()
+    assert F.dtype == torch.float32 and F.is_cuda and F.is_contiguous() and F.dim() == 2
+    Xk_d = torch.as_tensor(np.asarray(Xk, dtype=np.float64), device=F.device).contiguous()
+    out = torch.empty((grid.n, F.shape[1]), dtype=torch.float32, device=F.device)
+    _lib.check(lib.rtx_interp_knots(grid.byref(), None, grid.n, C.c_void_p(Xk_d.data_ptr()), Xk_d.numel(),
+                                    C.c_void_p(F.data_ptr()), F.shape[1], C.c_void_p(out.data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+def mako_bands(x_min, x_max, resFactor=None, fwhm_sf=1.0, shift=0.0, scale=1.0):
+    """Band axis, centres and triangle widths of rt.ILS_MAKO (radiative_transfer.py:1226-1241)."""
+    X_out = _MAKO_UM.copy()
+    if resFactor is not None:
+        X_out = np.interp(np.linspace(0, 1, int(len(X_out) * resFactor)), np.linspace(0, 1, len(X_out)), X_out)
+    X_out = np.sort(10000.0 / X_out)
+    X_out = X_out[(X_out > x_min) & (X_out < x_max)]
+    sigma = fwhm_sf * np.abs(np.gradient(X_out)) * 1.6
+    return X_out, scale * X_out + shift, sigma
+
+
+def band_radiance(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, keep_hires=False):
+    """C4: L_b,k = ILS_MAKO( tau*(eps_k*B(Ts) + (1-eps_k)*Ld) + La ) for every emissivity column k.
+
+    grid: engine.Grid of the monochromatic axis (e.g. the MAKO span of the C3 grid);
+    tau, La, Ld: [grid.n] float32 device tensors; Xk [nk], emis_knots [nk][nE] float32 device; Ts scalar [K].
+    Returns (X_out [nB] NumPy, L [nB][nE] float32 device). Three streaming kernels:
+    rtx_interp_knots -> rtx_apparent_radiance -> rtx_ils."""
+    dev = tau.device
+    em = interp_knots(grid, Xk, emis_knots)  # [nX][nE]
+    X_d = torch.as_tensor(grid.axis(), device=dev)
+    Ts_d = torch.as_tensor(np.atleast_1d(np.asarray(Ts, dtype=np.float64)), device=dev)
+    col = lambda v: v.reshape(-1, 1).contiguous()
+    L, _ = engine.apparent_radiance(X_d, em, Ts_d, col(tau), col(La), col(Ld))
+    L = L.reshape(grid.n, -1)  # [nX][nE] (nA = nT = 1)
+    X_out, centre, sigma = mako_bands(grid.axis()[0], grid.axis()[-1], resFactor)
+    out = engine.ils(0, L, torch.as_tensor(centre, device=dev), torch.as_tensor(sigma, device=dev), grid=grid)
+    return (X_out, out, L) if keep_hires else (X_out, out)

@@ -290,6 +290,36 @@ def test_ils_many_spectra_and_edges(rt):
     assert rel_err(yo[ok], yr[ok]) <= TOL_L
 
 
+# ------------------------------------------------ C4: knots -> grid -> at-sensor radiance -> MAKO bands
+def test_c4_band_radiance_vs_oracle(rt):
+    """Config C4 at a size the oracle finishes in seconds: 40 emissivities on the ASTER-DB knots,
+    760-1320 cm^-1 at 0.01 cm^-1, smooth synthetic TUD; device pipeline vs np.interp + the oracle's
+    compute_LWIR_apparent_radiance + ILS_MAKO."""
+    import torch
+    from radtxfr_amd import engine, sensor
+    Xe, em = synthetic.synth_emissivities(n_emis=40)
+    grid = engine.Grid(760.0, 1320.0, 56000)
+    X = grid.axis()
+    tau = 0.5 + 0.45 * np.sin(X / 13.0)
+    La = 2.0 + np.cos(X / 29.0)
+    Ld = 4.0 + 2.0 * np.sin(X / 7.0)
+    dev = torch.device("cuda")
+    f32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32), device=dev)
+    em_hi = sensor.interp_knots(grid, Xe, f32(em))
+    em_ref = np.stack([np.interp(X, Xe, em[:, k]) for k in range(em.shape[1])], axis=1)
+    assert rel_err(em_hi.cpu().numpy(), em_ref) <= 1e-6
+    xo, Lb = sensor.band_radiance(grid, f32(tau), f32(La), f32(Ld), Xe, f32(em), 287.87)
+    L_ref = ref.compute_LWIR_apparent_radiance(X, em_ref, np.array([287.87]), tau[:, None], La[:, None], Ld[:, None])[:, :, 0]
+    xr, Lb_ref = ref.ILS_MAKO(X, L_ref)
+    assert np.array_equal(xo, xr) and Lb.shape == Lb_ref.shape
+    assert rel_err(Lb.cpu().numpy(), Lb_ref) <= TOL_L
+    # np.interp end-value hold outside the knots
+    g2 = engine.Grid(600.0, 700.0, 1001)
+    e2 = sensor.interp_knots(g2, Xe, f32(em)).cpu().numpy()
+    r2 = np.stack([np.interp(g2.axis(), Xe, em[:, k]) for k in range(em.shape[1])], axis=1)
+    assert rel_err(e2, r2) <= 1e-6
+
+
 # --------------------------------------------------------- size-independent properties at full size
 def test_full_c3_width_properties():
     """5.5 M-point C3 grid x 32 layers at full size: properties that need no oracle run.
