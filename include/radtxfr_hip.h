@@ -112,6 +112,16 @@ int rtx_planck(const rtx_grid* grid, const double* X, int64_t nx, const double* 
                int wavelength, double* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Brightness temperature and its inverse. Replace brightnessTemperature(),
+ * radiative_transfer.py:851-933, and BT2L(), :936-1014 (fp64; bad_value where the reference masks:
+ * non-finite or non-positive radiance :922-923, non-finite radiance or T<=0 :1004-1005).
+ *   X[nx] fp64; in/out [nx][m] fp64, spectral axis first. */
+int rtx_brightness_temperature(const double* X, int64_t nx, const double* L, int64_t m,
+                               int wavelength, double bad_value, double* T_out, void* stream);
+int rtx_bt2l(const double* X, int64_t nx, const double* T, int64_t m, int wavelength,
+             double bad_value, double* L_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * TUD integration. Replaces the body of compute_TUD after the OD loop,
  * radiative_transfer.py:340-392: on-the-fly Planck, tau, upwelling recurrence (:346-356),
  * N_angle-stream downwelling recurrence and its cos*sin average (:368-389).
@@ -158,6 +168,22 @@ int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t nx, const f
  *   Outside [Xk[0], Xk[nk-1]] the end values are held, like np.interp. */
 int rtx_interp_knots(const rtx_grid* grid, const double* X, int64_t nx, const double* Xk,
                      int64_t nk, const float* F, int64_t nS, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused at-sensor band radiances for MANY emissivity spectra given on knots (config C4):
+ *   L[b][k] = ILS_b( tau*(eps_k*B(Ts) + (1-eps_k)*Ld) + La ),  eps_k = np.interp(X, Xk, E[:,k]).
+ * = compute_LWIR_apparent_radiance (radiative_transfer.py:1064-1068, nA = 1, no dT) followed by
+ * ILS_MAKO (:1236-1256 / ILS_MAKO.py:21-33), evaluated as (C_b + sum_j M[b][j] E[j][k]) / N_b:
+ * rtx_band_moments makes ONE pass over the monochromatic tau/La/Ld (uniform grid) and writes
+ *   N[nB], C[nB], M[nB][nk] float32 and jrange[nB][2] int32 (first/last knot each band touches);
+ * rtx_band_mix contracts them with E[nk][nE] float32 -> out[nB][nE] float32.
+ * Nothing of size nX*nE is ever formed (the reference needs a 1.4 TB temporary for this). */
+int rtx_band_moments(int kind, const rtx_grid* grid, const float* tau, const float* La,
+                     const float* Ld, double Ts, const double* Xk, int64_t nk, int nB,
+                     const double* centre, const double* sigma, float* N_out, float* C_out,
+                     float* M_out, int32_t* jrange_out, void* stream);
+int rtx_band_mix(const float* N, const float* C, const float* M, const int32_t* jrange, int nB,
+                 int64_t nk, const float* E, int64_t nE, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,10 @@ PROTOTYPES = {
     "rtx_apparent_radiance": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "rtx_ils": (_i32, [_i32, _gp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "rtx_interp_knots": (_i32, [_gp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "rtx_band_moments": (_i32, [_i32, _gp, _vp, _vp, _vp, _dbl, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rtx_band_mix": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp]),
+    "rtx_brightness_temperature": (_i32, [_vp, _i64, _vp, _i64, _i32, _dbl, _vp, _vp]),
+    "rtx_bt2l": (_i32, [_vp, _i64, _vp, _i64, _i32, _dbl, _vp, _vp]),
 }
 
 _lib = None

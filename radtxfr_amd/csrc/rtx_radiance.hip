@@ -231,10 +231,16 @@ __global__ __launch_bounds__(256) void ils_columns_kernel(IlsArgs a) {
   const long long lo = ils_bound(a, c - R, 1), hi = ils_bound(a, c + R, 0);
   float acc = 0.f, wsum = 0.f;
   const bool live = col < a.nS;
-  for (long long i = lo + wave; i < hi; i += 4) {
-    const float w = ils_weight(a.kind, ils_x(a, i), c, s);
-    wsum += w;
-    if (live) acc = fmaf(w, a.Y[i * a.ldY + col], acc);
+  for (long long i0 = lo + wave; i0 < hi; i0 += 256) {  // two-level sums (64 rows per block)
+    float pa = 0.f, pw = 0.f;
+    const long long blk_end = i0 + 256 < hi ? i0 + 256 : hi;
+    for (long long i = i0; i < blk_end; i += 4) {
+      const float w = ils_weight(a.kind, ils_x(a, i), c, s);
+      pw += w;
+      if (live) pa = fmaf(w, a.Y[i * a.ldY + col], pa);
+    }
+    acc += pa;
+    wsum += pw;
   }
   __shared__ float s_acc[4][64];
   __shared__ float s_w[4];
@@ -261,21 +267,29 @@ __global__ __launch_bounds__(256) void ils_columns4_kernel(IlsArgs a) {
   const long long lo = ils_bound(a, c - R, 1), hi = ils_bound(a, c + R, 0);
   const bool live = col4 < nS4;
   const float4* Y4 = reinterpret_cast<const float4*>(a.Y) + (live ? col4 : 0);
+  // two-level sums: a wave adds up to ~6000 rows per band; 64-row blocks keep the fp32 error at ~1e-7
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float wsum = 0.f;
   long long i = lo + wave;
-  for (; i + 4 < hi; i += 8) {  // two rows in flight per wave
-    const float w0 = ils_weight(a.kind, ils_x(a, i), c, s), w1 = ils_weight(a.kind, ils_x(a, i + 4), c, s);
-    const float4 y0 = Y4[i * ld4], y1 = Y4[(i + 4) * ld4];
-    wsum += w0 + w1;
-    acc.x = fmaf(w0, y0.x, acc.x); acc.y = fmaf(w0, y0.y, acc.y); acc.z = fmaf(w0, y0.z, acc.z); acc.w = fmaf(w0, y0.w, acc.w);
-    acc.x = fmaf(w1, y1.x, acc.x); acc.y = fmaf(w1, y1.y, acc.y); acc.z = fmaf(w1, y1.z, acc.z); acc.w = fmaf(w1, y1.w, acc.w);
-  }
-  for (; i < hi; i += 4) {
-    const float w0 = ils_weight(a.kind, ils_x(a, i), c, s);
-    const float4 y0 = Y4[i * ld4];
-    wsum += w0;
-    acc.x = fmaf(w0, y0.x, acc.x); acc.y = fmaf(w0, y0.y, acc.y); acc.z = fmaf(w0, y0.z, acc.z); acc.w = fmaf(w0, y0.w, acc.w);
+  while (i < hi) {
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pw = 0.f;
+    const long long blk_end = i + 256 < hi ? i + 256 : hi;
+    for (; i + 4 < blk_end; i += 8) {  // two rows in flight per wave
+      const float w0 = ils_weight(a.kind, ils_x(a, i), c, s), w1 = ils_weight(a.kind, ils_x(a, i + 4), c, s);
+      const float4 y0 = Y4[i * ld4], y1 = Y4[(i + 4) * ld4];
+      pw += w0 + w1;
+      pa.x = fmaf(w0, y0.x, pa.x); pa.y = fmaf(w0, y0.y, pa.y); pa.z = fmaf(w0, y0.z, pa.z); pa.w = fmaf(w0, y0.w, pa.w);
+      pa.x = fmaf(w1, y1.x, pa.x); pa.y = fmaf(w1, y1.y, pa.y); pa.z = fmaf(w1, y1.z, pa.z); pa.w = fmaf(w1, y1.w, pa.w);
+    }
+    for (; i < blk_end; i += 4) {
+      const float w0 = ils_weight(a.kind, ils_x(a, i), c, s);
+      const float4 y0 = Y4[i * ld4];
+      pw += w0;
+      pa.x = fmaf(w0, y0.x, pa.x); pa.y = fmaf(w0, y0.y, pa.y); pa.z = fmaf(w0, y0.z, pa.z); pa.w = fmaf(w0, y0.w, pa.w);
+    }
+    acc.x += pa.x; acc.y += pa.y; acc.z += pa.z; acc.w += pa.w;
+    wsum += pw;
   }
   __shared__ float4 s_acc[4][64];
   __shared__ float s_w[4];
@@ -397,6 +411,165 @@ extern "C" int rtx_interp_knots(const rtx_grid* grid, const double* X, int64_t n
   const long long groups = (nx + 63) / 64;
   const long long blocks = groups < 256 * 16 ? groups : 256 * 16;
   hipLaunchKernelGGL(interp_knots_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused C4 (SURVEY 8d row "C+D fused"): band radiances of MANY emissivity spectra given on knots, without
+// materialising anything at monochromatic resolution.
+//   L_b,k = sum_i w_b(i) [ tau_i (eps_k(nu_i) B_i + (1 - eps_k(nu_i)) Ld_i) + La_i ] / sum_i w_b(i)
+// with eps_k(nu_i) = (1-f_i) E[j(i)][k] + f_i E[j(i)+1][k] (np.interp) is linear in the knot values, so
+//   L_b,k = ( C_b + sum_j M[b][j] E[j][k] ) / N_b,
+//   N_b = sum_i w_i,  C_b = sum_i w_i (tau_i Ld_i + La_i),  M[b][j] = sum over the two knot intervals touching j of
+//   w_i tau_i (B_i - Ld_i) times the hat function of knot j at nu_i.
+// rtx_band_moments does the monochromatic pass once (wavefront reductions per knot interval, fixed order:
+// deterministic); rtx_band_mix is the tiny [nB x nk] x [nk x nE] contraction restricted to each band's knots.
+struct MomArgs {
+  int kind;
+  GridDev g;
+  long long nx;
+  const float *tau, *La, *Ld;
+  double c2l2e_over_T;  // 100*c2*log2(e)/Ts
+  const double* Xk;
+  long long nk;
+  int nB;
+  const double* centre;
+  const double* sigma;
+  float* N;      // [nB]
+  float* C;      // [nB]
+  float* M;      // [nB][nk]
+  int2* jrange;  // [nB] first / last knot with a non-zero M
+};
+
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// first grid index with X[i] >= v (uniform grid only)
+__device__ long long grid_lower_bound(const GridDev& g, long long n, double v) {
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (grid_x(g, g.offset + mid) >= v) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void band_moments_kernel(MomArgs a) {
+  __shared__ float s_red[4];
+  const int b = blockIdx.x;
+  const double c = a.centre[b], s = a.sigma[b];
+  const double R = a.kind == 0 ? s : 14.0 * s;
+  // support: X > c-R and X < c+R  (open interval, like tri() and the ILS kernels)
+  long long lo = grid_lower_bound(a.g, a.nx, c - R);
+  while (lo < a.nx && !(grid_x(a.g, a.g.offset + lo) > c - R)) ++lo;
+  const long long hi = grid_lower_bound(a.g, a.nx, c + R);
+  float* Mrow = a.M + (size_t)b * a.nk;
+  for (long long j = threadIdx.x; j < a.nk; j += blockDim.x) Mrow[j] = 0.f;
+  float Nsum = 0.f, Csum = 0.f;  // per-thread partials over the whole band
+  int jfirst = 0x7fffffff, jlast = -1;
+  // knot intervals jj = -1 (left of the first knot) .. nk-1 (right of the last): np.interp holds the end values
+  long long p_lo = lo;
+  // first interval that can contain X[lo]: jj = (#knots <= X[lo]) - 1
+  long long jj;
+  {
+    const double x_first = lo < a.nx ? grid_x(a.g, a.g.offset + lo) : 0.0;
+    long long l2 = 0, h2 = a.nk;
+    while (l2 < h2) { const long long mid = (l2 + h2) >> 1; if (a.Xk[mid] <= x_first) l2 = mid + 1; else h2 = mid; }
+    jj = l2 - 1;
+  }
+  while (p_lo < hi) {
+    // points of this interval: X < Xk[jj+1]
+    const long long p_hi = (jj + 1 < a.nk) ? min(hi, grid_lower_bound(a.g, a.nx, a.Xk[jj + 1])) : hi;
+    const long long j0 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj);
+    const long long j1 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj + 1);
+    const double x0 = a.Xk[j0], dxk = a.Xk[j1] - a.Xk[j0];
+    float G0 = 0.f, G1 = 0.f;
+    for (long long i = p_lo + threadIdx.x; i < p_hi; i += blockDim.x) {
+      const double x = grid_x(a.g, a.g.offset + i);
+      const float w = ils_weight(a.kind, x, c, s);
+      const double x100 = x * 100.0;
+      const float B = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, a.c2l2e_over_T);
+      const float t = a.tau[i], ld = a.Ld[i];
+      const float f = dxk > 0.0 ? (float)((x - x0) / dxk) : 0.f;
+      const float gi = w * t * (B - ld);
+      Nsum += w;
+      Csum = fmaf(w, fmaf(t, ld, a.La[i]), Csum);
+      G1 = fmaf(gi, f, G1);
+      G0 = fmaf(gi, 1.0f - f, G0);
+    }
+    if (p_hi > p_lo) {
+      const float g0 = block_sum(G0, s_red), g1 = block_sum(G1, s_red);
+      if (threadIdx.x == 0) {  // one writer, intervals in ascending order: deterministic
+        Mrow[j0] += g0;
+        Mrow[j1] += g1;
+      }
+      jfirst = min(jfirst, (int)j0);
+      jlast = max(jlast, (int)j1);
+    }
+    p_lo = p_hi;
+    ++jj;
+  }
+  const float Nb = block_sum(Nsum, s_red), Cb = block_sum(Csum, s_red);
+  if (threadIdx.x == 0) {
+    a.N[b] = Nb;
+    a.C[b] = Cb;
+    a.jrange[b] = make_int2(jfirst == 0x7fffffff ? 0 : jfirst, jlast);
+  }
+}
+
+struct MixArgs {
+  const float *N, *C, *M;
+  const int2* jrange;
+  long long nk, nE;
+  const float* E;  // [nk][nE]
+  float* out;      // [nB][nE]
+};
+
+__global__ __launch_bounds__(256) void band_mix_kernel(MixArgs a) {
+  const int b = blockIdx.x;
+  const long long k = (long long)blockIdx.y * blockDim.x + threadIdx.x;
+  if (k >= a.nE) return;
+  const int2 jr = a.jrange[b];
+  const float* Mrow = a.M + (size_t)b * a.nk;
+  float acc = a.C[b];
+  for (int j = jr.x; j <= jr.y; ++j) acc = fmaf(Mrow[j], a.E[(size_t)j * a.nE + k], acc);
+  a.out[(size_t)b * a.nE + k] = acc / a.N[b];  // N = 0 -> NaN, as the unfused path
+}
+
+extern "C" int rtx_band_moments(int kind, const rtx_grid* grid, const float* tau, const float* La, const float* Ld, double Ts,
+                                const double* Xk, int64_t nk, int nB, const double* centre, const double* sigma,
+                                float* N_out, float* C_out, float* M_out, int32_t* jrange_out, void* stream) {
+  if (kind != 0 && kind != 1) RTX_FAIL("kind must be 0 (triangle) or 1 (Gaussian)");
+  if (rtx_check_grid(grid)) return 1;
+  if (nk < 2) RTX_FAIL("need at least 2 knots");
+  if (nB < 0) RTX_FAIL("negative size");
+  if (nB == 0) return 0;
+  if (!(Ts > 0.0)) RTX_FAIL("surface temperature %g", Ts);
+  if (!tau || !La || !Ld || !Xk || !centre || !sigma || !N_out || !C_out || !M_out || !jrange_out) RTX_FAIL("a required pointer is NULL");
+  MomArgs a;
+  a.kind = kind; a.g = to_dev(grid); a.nx = grid->n; a.tau = tau; a.La = La; a.Ld = Ld;
+  a.c2l2e_over_T = 100.0 * RT_C2 * 1.4426950408889634 / Ts;
+  a.Xk = Xk; a.nk = nk; a.nB = nB; a.centre = centre; a.sigma = sigma;
+  a.N = N_out; a.C = C_out; a.M = M_out; a.jrange = reinterpret_cast<int2*>(jrange_out);
+  hipLaunchKernelGGL(band_moments_kernel, dim3(nB), dim3(256), 0, (hipStream_t)stream, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rtx_band_mix(const float* N, const float* C, const float* M, const int32_t* jrange, int nB, int64_t nk,
+                            const float* E, int64_t nE, float* out, void* stream) {
+  if (nB < 0 || nE < 0 || nk < 1) RTX_FAIL("bad size");
+  if (nB == 0 || nE == 0) return 0;
+  if (!N || !C || !M || !jrange || !E || !out) RTX_FAIL("a required pointer is NULL");
+  MixArgs a;
+  a.N = N; a.C = C; a.M = M; a.jrange = reinterpret_cast<const int2*>(jrange); a.nk = nk; a.nE = nE; a.E = E; a.out = out;
+  hipLaunchKernelGGL(band_mix_kernel, dim3(nB, (unsigned)((nE + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }

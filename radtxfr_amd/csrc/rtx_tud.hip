@@ -74,6 +74,78 @@ extern "C" int rtx_planck(const rtx_grid* grid, const double* X, int64_t nx, con
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Inverse Planck and its forward twin on brightness temperatures: brightnessTemperature()
+// (radiative_transfer.py:851-933) and BT2L() (:936-1014). fp64, the reference's expressions and its
+// bad-value masking (:922-923, :1004-1005). in/out are [nx][m], spectral axis first.
+struct BtArgs {
+  const double* X;
+  long long nx, m;
+  const double* in;
+  int wavelength, inverse;  // inverse=1: radiance -> T ; 0: T -> radiance
+  double bad;
+  double* out;
+};
+
+__global__ __launch_bounds__(256) void bt_kernel(BtArgs a) {
+  const long long total = a.nx * a.m;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / a.m;
+    double X = a.X[i];
+    const double v = a.in[e];
+    double r;
+    bool bad;
+    if (a.inverse) {
+      double L = v;
+      if (a.wavelength) {
+        X = X * 1e-6;  L = L * 1e4;   // (:913-915)
+        r = RT_C2 / (X * log(1.0 + RT_C1 / (pow(X, 5.0) * L)));
+      } else {
+        X = X * 100.0;  L = L * 1e-4;  // (:917-919)
+        r = RT_C2 * X / log(RT_C1 * (X * X * X) / L + 1.0);
+      }
+      bad = !isfinite(L) || (L <= 0.0);
+    } else {
+      const double T = v;
+      if (a.wavelength) {
+        X = X * 1e-6;  // (:995-997)
+        r = RT_C1 / (pow(X, 5.0) * (exp(RT_C2 / (X * T)) - 1.0));
+        r *= 1e-4;
+      } else {
+        X = X * 100.0;  // (:999-1001)
+        r = RT_C1 * (X * X * X) / (exp(RT_C2 * X / T) - 1.0);
+        r *= 1e4;
+      }
+      bad = !isfinite(r) || (T <= 0.0);
+    }
+    a.out[e] = bad ? a.bad : r;
+  }
+}
+
+static int launch_bt(const double* X, int64_t nx, const double* in, int64_t m, int wavelength, int inverse, double bad,
+                     double* out, void* stream) {
+  if (nx < 0 || m < 0) RTX_FAIL("negative size");
+  if (nx == 0 || m == 0) return 0;
+  if (!X || !in || !out) RTX_FAIL("a required pointer is NULL");
+  BtArgs a;
+  a.X = X; a.nx = nx; a.m = m; a.in = in; a.wavelength = wavelength; a.inverse = inverse; a.bad = bad; a.out = out;
+  long long blocks = (nx * m + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(bt_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rtx_brightness_temperature(const double* X, int64_t nx, const double* L, int64_t m, int wavelength,
+                                          double bad_value, double* T_out, void* stream) {
+  return launch_bt(X, nx, L, m, wavelength, 1, bad_value, T_out, stream);
+}
+
+extern "C" int rtx_bt2l(const double* X, int64_t nx, const double* T, int64_t m, int wavelength, double bad_value,
+                        double* L_out, void* stream) {
+  return launch_bt(X, nx, T, m, wavelength, 0, bad_value, L_out, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
 #define TUD_MAX_LAYERS 128
 #define TUD_MAX_ANGLES 128
 #define TUD_MAX_ALT 16

@@ -65,8 +65,16 @@ class Grid:
 
     def axis(self):
         """Materialise this shard's wavenumbers (host fp64), bit-identical to np.linspace."""
-        X = np.linspace(self.xmin, self.xmax, self.n_total)
-        return X[self.offset:self.offset + self.n]
+        ig = np.arange(self.offset, self.offset + self.n, dtype=np.float64)
+        X = ig * self.step + self.xmin  # arange*step + start: the two roundings np.linspace makes
+        if self.n and self.offset + self.n == self.n_total:
+            X[-1] = self.xmax
+        return X
+
+    def x_at(self, i):
+        """Wavenumber of local index i (same bits as axis()[i])."""
+        ig = self.offset + int(i)
+        return self.xmax if ig == self.n_total - 1 else float(np.float64(ig) * self.step + self.xmin)
 
     @staticmethod
     def from_axis(X, rtol=1e-9):

@@ -37,6 +37,34 @@ def mako_bands(x_min, x_max, resFactor=None, fwhm_sf=1.0, shift=0.0, scale=1.0):
     return X_out, scale * X_out + shift, sigma
 
 
+def band_radiance_fused(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, kind=0):
+    """Same result as band_radiance() without any [nX][nE] array: one monochromatic pass
+    (rtx_band_moments) + a [nB x nk] x [nk x nE] contraction over each band's ~10-30 knots (rtx_band_mix).
+    Returns (X_out [nB] NumPy, L [nB][nE] float32 device)."""
+    lib = _lib.load()
+    dev = tau.device
+    if kind == 0:
+        X_out, centre, sigma = mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
+    else:  # Gaussian variant: no clipping, sigma = |gradient| (ILS_MAKO.py:19-21)
+        X_out = np.sort(10000.0 / _MAKO_UM)
+        centre, sigma = X_out, np.abs(np.gradient(X_out))
+    nB, nk, nE = X_out.size, len(Xk), emis_knots.shape[1]
+    assert emis_knots.dtype == torch.float32 and emis_knots.is_contiguous() and emis_knots.shape[0] == nk
+    Xk_d = torch.as_tensor(np.asarray(Xk, dtype=np.float64), device=dev)
+    c_d, s_d = torch.as_tensor(centre, device=dev), torch.as_tensor(sigma, device=dev)
+    N = torch.empty(nB, dtype=torch.float32, device=dev)
+    Cb = torch.empty(nB, dtype=torch.float32, device=dev)
+    M = torch.empty((nB, nk), dtype=torch.float32, device=dev)
+    jr = torch.empty((nB, 2), dtype=torch.int32, device=dev)
+    out = torch.empty((nB, nE), dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rtx_band_moments(int(kind), grid.byref(), p(tau), p(La), p(Ld), float(Ts), p(Xk_d), nk, nB, p(c_d), p(s_d),
+                                    p(N), p(Cb), p(M), p(jr), st))
+    _lib.check(lib.rtx_band_mix(p(N), p(Cb), p(M), p(jr), nB, nk, p(emis_knots), nE, p(out), st))
+    return X_out, out
+
+
 def band_radiance(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, keep_hires=False):
     """C4: L_b,k = ILS_MAKO( tau*(eps_k*B(Ts) + (1-eps_k)*Ld) + La ) for every emissivity column k.
 

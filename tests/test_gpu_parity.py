@@ -60,6 +60,31 @@ def test_g1_planckian(rt, golden):
     np.testing.assert_allclose(rt.planckian(np.array([10.0]), 300.0)[0], 9.924016798845834e+02, rtol=1e-12)
 
 
+def test_g1_brightness_temperature_and_bt2l(rt, golden):
+    g = golden("g1_planck.npz")
+    BT = rt.brightnessTemperature(g["X"], g["L32"])
+    assert BT.shape == g["BT"].shape
+    np.testing.assert_allclose(BT, g["BT"], rtol=1e-12)
+    np.testing.assert_allclose(rt.brightnessTemperature(g["Xum"], g["Lum"], wavelength=True), g["BTum"], rtol=1e-12)
+    T8 = np.tile(g["T32"][None, :8], (g["X"].size, 1))
+    np.testing.assert_allclose(rt.BT2L(g["X"], T8), g["L_bt2l"], rtol=1e-12)
+    # round trip, 1-D quirk (a vector comes back (nX,1)), spectral_dim, bad-value masking (:922-923, :1004-1005)
+    L1 = rt.planckian(g["X"], 300.0)
+    T1 = rt.brightnessTemperature(g["X"], L1)
+    assert T1.shape == (g["X"].size, 1)
+    np.testing.assert_allclose(T1[:, 0], 300.0, rtol=1e-12)
+    np.testing.assert_allclose(rt.brightnessTemperature(g["X"], g["L32"].T, spectral_dim=1), g["BT"].T, rtol=1e-12)
+    Lb = g["L32"].copy()
+    Lb[3, 2], Lb[5, 0], Lb[7, 1] = -1.0, 0.0, np.inf
+    Tb = rt.brightnessTemperature(g["X"], Lb, bad_value=-99.0)
+    Tr = ref.brightnessTemperature(g["X"], Lb, bad_value=-99.0)
+    assert Tb[3, 2] == Tb[5, 0] == Tb[7, 1] == -99.0
+    np.testing.assert_allclose(Tb, Tr, rtol=1e-12)
+    Tn = T8.copy()
+    Tn[2, 2] = -5.0
+    np.testing.assert_allclose(rt.BT2L(g["X"], Tn, bad_value=0.0), ref.BT2L(g["X"], Tn, bad_value=0.0), rtol=1e-12)
+
+
 # --------------------------------------------------------------------- G4 absorptionCoefficient_Voigt
 def _g4_table(hapi, g):
     tbl = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
@@ -313,6 +338,18 @@ def test_c4_band_radiance_vs_oracle(rt):
     xr, Lb_ref = ref.ILS_MAKO(X, L_ref)
     assert np.array_equal(xo, xr) and Lb.shape == Lb_ref.shape
     assert rel_err(Lb.cpu().numpy(), Lb_ref) <= TOL_L
+    # fused form (no [nX][nE] array): same numbers, also at resFactor=2 and on an axis that sticks out of the knots
+    xf, Lf = sensor.band_radiance_fused(grid, f32(tau), f32(La), f32(Ld), Xe, f32(em), 287.87)
+    assert np.array_equal(xf, xr) and rel_err(Lf.cpu().numpy(), Lb_ref) <= TOL_L
+    xr2, Lb_ref2 = ref.ILS_MAKO(X, L_ref, resFactor=2)
+    xf2, Lf2 = sensor.band_radiance_fused(grid, f32(tau), f32(La), f32(Ld), Xe, f32(em), 287.87, resFactor=2)
+    assert np.array_equal(xf2, xr2) and rel_err(Lf2.cpu().numpy(), Lb_ref2) <= TOL_L
+    Xs = Xe[200:420]  # knots cover only 888..1108 cm^-1: np.interp holds the end values outside
+    em_s = np.stack([np.interp(X, Xs, em[200:420, k]) for k in range(em.shape[1])], axis=1)
+    L_s = ref.compute_LWIR_apparent_radiance(X, em_s, np.array([287.87]), tau[:, None], La[:, None], Ld[:, None])[:, :, 0]
+    _, Lb_s = ref.ILS_MAKO(X, L_s)
+    _, Lf_s = sensor.band_radiance_fused(grid, f32(tau), f32(La), f32(Ld), Xs, f32(em[200:420]), 287.87)
+    assert rel_err(Lf_s.cpu().numpy(), Lb_s) <= TOL_L
     # np.interp end-value hold outside the knots
     g2 = engine.Grid(600.0, 700.0, 1001)
     e2 = sensor.interp_knots(g2, Xe, f32(em)).cpu().numpy()
