@@ -185,6 +185,30 @@ int rtx_band_moments(int kind, const rtx_grid* grid, const float* tau, const flo
 int rtx_band_mix(const float* N, const float* C, const float* M, const int32_t* jrange, int nB,
                  int64_t nk, const float* E, int64_t nE, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused HSI cube (config C5): every pixel has its own emissivity mixture and surface temperature
+ * (LWIR_HSI_Generator.py:151-167: em = mixFrac . emis[ix_em], T = Ts + dT*N(0,1),
+ * L = tau*(em*B(T) + (1-em)*Ld) + La), evaluated at monochromatic resolution and passed through
+ * the ILS. B(nu, T_p) is interpolated over each band's support through Q Chebyshev nodes
+ * (Q = 5: < 2e-10 relative), which makes the monochromatic pass pixel-independent:
+ *   rtx_band_basis_moments -> N[nB], C[nB], MLd[nB][nk], MB[Q][nB][nk], jrange[nB][2]
+ *       basis_coef_h[Q][Q]: monomial coefficients of the Lagrange basis l_q(s), s = (nu-c_b)/(node_span*sigma_b)
+ *   rtx_band_mix (N = C = NULL) contracts MLd / each MB[q] with the endmember knot spectra E[nk][nEnd]
+ *       -> ALd[nB][nEnd], AB[Q][nB][nEnd]
+ *   rtx_pixel_cube -> cube[nB][nPix] float32 (bands first):
+ *       kidx[nPix][nMix] int32 endmember indices, frac[nPix][nMix] float32, Tpix[nPix] fp64 (device);
+ *       s_node_h[Q] the Chebyshev nodes in s. */
+int rtx_band_basis_moments(int kind, const rtx_grid* grid, const float* tau, const float* La,
+                           const float* Ld, const double* Xk, int64_t nk, int nB,
+                           const double* centre, const double* sigma, int Q,
+                           const float* basis_coef_h, double node_span, float* N_out,
+                           float* C_out, float* MLd_out, float* MB_out, int32_t* jrange_out,
+                           void* stream);
+int rtx_pixel_cube(int nB, int Q, const double* centre, const double* sigma, double node_span,
+                   const float* s_node_h, const float* N, const float* C, const float* ALd,
+                   const float* AB, int nEnd, int64_t nPix, int nMix, const int32_t* kidx,
+                   const float* frac, const double* Tpix, float* cube, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -537,9 +537,9 @@ __global__ __launch_bounds__(256) void band_mix_kernel(MixArgs a) {
   if (k >= a.nE) return;
   const int2 jr = a.jrange[b];
   const float* Mrow = a.M + (size_t)b * a.nk;
-  float acc = a.C[b];
+  float acc = a.C ? a.C[b] : 0.f;
   for (int j = jr.x; j <= jr.y; ++j) acc = fmaf(Mrow[j], a.E[(size_t)j * a.nE + k], acc);
-  a.out[(size_t)b * a.nE + k] = acc / a.N[b];  // N = 0 -> NaN, as the unfused path
+  a.out[(size_t)b * a.nE + k] = a.N ? acc / a.N[b] : acc;  // N = 0 -> NaN, as the unfused path
 }
 
 extern "C" int rtx_band_moments(int kind, const rtx_grid* grid, const float* tau, const float* La, const float* Ld, double Ts,
@@ -566,10 +566,208 @@ extern "C" int rtx_band_mix(const float* N, const float* C, const float* M, cons
                             const float* E, int64_t nE, float* out, void* stream) {
   if (nB < 0 || nE < 0 || nk < 1) RTX_FAIL("bad size");
   if (nB == 0 || nE == 0) return 0;
-  if (!N || !C || !M || !jrange || !E || !out) RTX_FAIL("a required pointer is NULL");
+  if (!M || !jrange || !E || !out) RTX_FAIL("a required pointer is NULL");  // N, C may be NULL: plain contraction
   MixArgs a;
   a.N = N; a.C = C; a.M = M; a.jrange = reinterpret_cast<const int2*>(jrange); a.nk = nk; a.nE = nE; a.E = E; a.out = out;
   hipLaunchKernelGGL(band_mix_kernel, dim3(nB, (unsigned)((nE + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused C5: an HSI cube -- every pixel has its own linear emissivity mixture AND its own surface
+// temperature T_p (LWIR_HSI_Generator.py:151-167) -- at monochromatic resolution followed by the ILS.
+//   L_b,p = [ C_b + sum_m f_pm ( sum_i w tau B(nu_i,T_p) eps_km(nu_i) - sum_i w tau Ld eps_km(nu_i) ) ] / N_b
+// B(nu, T_p) is the only pixel-dependent factor inside the monochromatic sum. Over the support of one band
+// (a few cm^-1 to ~25 cm^-1) it is a very smooth function of nu, so it is replaced by its degree-(Q-1)
+// interpolant through Q Chebyshev nodes of the band:  B(nu,T) = sum_q l_q(s) B(nu_bq, T),  s = (nu-c_b)/R_b.
+// For Q = 5 the interpolation error is < 2e-10 relative (|d ln B/d nu| < 5e-3 per cm^-1), three orders below
+// fp32 rounding. Then
+//   L_b,p = [ C_b + sum_m f_pm ( sum_q B(nu_bq,T_p) AB[q][b][k_m] - ALd[b][k_m] ) ] / N_b
+// with pixel-independent tables from ONE monochromatic pass: MB[q][b][j] = sum_i w tau l_q hat_j,
+// MLd[b][j] = sum_i w tau Ld hat_j (rtx_band_basis_moments), contracted with the endmember knot spectra
+// (rtx_band_mix), and a per-(band, pixel) kernel with Q Planck evaluations (rtx_pixel_cube).
+#define CUBE_QMAX 6
+struct BasisArgs {
+  int kind, Q;
+  GridDev g;
+  long long nx;
+  const float *tau, *La, *Ld;
+  const double* Xk;
+  long long nk;
+  int nB;
+  const double* centre;
+  const double* sigma;
+  float coef[CUBE_QMAX][CUBE_QMAX];  // l_q(s) = sum_d coef[q][d] s^d
+  float node_span;                   // R_b = node_span * sigma_b
+  float* N;
+  float* C;
+  float* MLd;  // [nB][nk]
+  float* MB;   // [Q][nB][nk]
+  int2* jrange;
+};
+
+__global__ __launch_bounds__(256) void band_basis_moments_kernel(BasisArgs a) {
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, Q = a.Q;
+  const double c = a.centre[b], s = a.sigma[b];
+  const double R = a.kind == 0 ? s : 14.0 * s;
+  const double inv_Rn = 1.0 / ((double)a.node_span * s);
+  long long lo = grid_lower_bound(a.g, a.nx, c - R);
+  while (lo < a.nx && !(grid_x(a.g, a.g.offset + lo) > c - R)) ++lo;
+  const long long hi = grid_lower_bound(a.g, a.nx, c + R);
+  float* MLd = a.MLd + (size_t)b * a.nk;
+  for (long long j = threadIdx.x; j < a.nk; j += blockDim.x) {
+    MLd[j] = 0.f;
+    for (int q = 0; q < Q; ++q) a.MB[((size_t)q * a.nB + b) * a.nk + j] = 0.f;
+  }
+  float Nsum = 0.f, Csum = 0.f;
+  int jfirst = 0x7fffffff, jlast = -1;
+  long long p_lo = lo, jj;
+  {
+    const double x_first = lo < a.nx ? grid_x(a.g, a.g.offset + lo) : 0.0;
+    long long l2 = 0, h2 = a.nk;
+    while (l2 < h2) { const long long mid = (l2 + h2) >> 1; if (a.Xk[mid] <= x_first) l2 = mid + 1; else h2 = mid; }
+    jj = l2 - 1;
+  }
+  while (p_lo < hi) {
+    const long long p_hi = (jj + 1 < a.nk) ? min(hi, grid_lower_bound(a.g, a.nx, a.Xk[jj + 1])) : hi;
+    const long long j0 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj);
+    const long long j1 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj + 1);
+    const double x0 = a.Xk[j0], dxk = a.Xk[j1] - a.Xk[j0];
+    float G0[CUBE_QMAX + 1], G1[CUBE_QMAX + 1];  // [0..Q-1]: basis moments, [Q]: the Ld moment
+#pragma unroll
+    for (int q = 0; q <= CUBE_QMAX; ++q) G0[q] = G1[q] = 0.f;
+    for (long long i = p_lo + threadIdx.x; i < p_hi; i += blockDim.x) {
+      const double x = grid_x(a.g, a.g.offset + i);
+      const float w = ils_weight(a.kind, x, c, s);
+      const float t = a.tau[i], ld = a.Ld[i];
+      const float f = dxk > 0.0 ? (float)((x - x0) / dxk) : 0.f;
+      const float sn = (float)((x - c) * inv_Rn);
+      const float wt = w * t;
+      Nsum += w;
+      Csum = fmaf(w, fmaf(t, ld, a.La[i]), Csum);
+#pragma unroll
+      for (int q = 0; q < CUBE_QMAX; ++q) {
+        if (q < Q) {
+          float l = a.coef[q][CUBE_QMAX - 1];
+#pragma unroll
+          for (int d = CUBE_QMAX - 2; d >= 0; --d) l = fmaf(l, sn, a.coef[q][d]);
+          const float gq = wt * l;
+          G1[q] = fmaf(gq, f, G1[q]);
+          G0[q] = fmaf(gq, 1.0f - f, G0[q]);
+        }
+      }
+      const float gl = wt * ld;
+      G1[CUBE_QMAX] = fmaf(gl, f, G1[CUBE_QMAX]);
+      G0[CUBE_QMAX] = fmaf(gl, 1.0f - f, G0[CUBE_QMAX]);
+    }
+    if (p_hi > p_lo) {
+#pragma unroll
+      for (int q = 0; q <= CUBE_QMAX; ++q) {
+        if (q < Q || q == CUBE_QMAX) {
+          const float g0 = block_sum(G0[q], s_red), g1 = block_sum(G1[q], s_red);
+          if (threadIdx.x == 0) {
+            float* row = (q == CUBE_QMAX) ? MLd : a.MB + ((size_t)q * a.nB + b) * a.nk;
+            row[j0] += g0;
+            row[j1] += g1;
+          }
+        }
+      }
+      jfirst = min(jfirst, (int)j0);
+      jlast = max(jlast, (int)j1);
+    }
+    p_lo = p_hi;
+    ++jj;
+  }
+  const float Nb = block_sum(Nsum, s_red), Cb = block_sum(Csum, s_red);
+  if (threadIdx.x == 0) {
+    a.N[b] = Nb;
+    a.C[b] = Cb;
+    a.jrange[b] = make_int2(jfirst == 0x7fffffff ? 0 : jfirst, jlast);
+  }
+}
+
+extern "C" int rtx_band_basis_moments(int kind, const rtx_grid* grid, const float* tau, const float* La, const float* Ld,
+                                      const double* Xk, int64_t nk, int nB, const double* centre, const double* sigma, int Q,
+                                      const float* basis_coef_h, double node_span, float* N_out, float* C_out, float* MLd_out,
+                                      float* MB_out, int32_t* jrange_out, void* stream) {
+  if (kind != 0 && kind != 1) RTX_FAIL("kind must be 0 (triangle) or 1 (Gaussian)");
+  if (rtx_check_grid(grid)) return 1;
+  if (nk < 2) RTX_FAIL("need at least 2 knots");
+  if (Q < 1 || Q > CUBE_QMAX) RTX_FAIL("Q=%d outside [1,%d]", Q, CUBE_QMAX);
+  if (nB < 0) RTX_FAIL("negative size");
+  if (nB == 0) return 0;
+  if (!(node_span > 0.0)) RTX_FAIL("node_span must be > 0");
+  if (!tau || !La || !Ld || !Xk || !centre || !sigma || !basis_coef_h || !N_out || !C_out || !MLd_out || !MB_out || !jrange_out)
+    RTX_FAIL("a required pointer is NULL");
+  BasisArgs a;
+  a.kind = kind; a.Q = Q; a.g = to_dev(grid); a.nx = grid->n; a.tau = tau; a.La = La; a.Ld = Ld; a.Xk = Xk; a.nk = nk; a.nB = nB;
+  a.centre = centre; a.sigma = sigma; a.node_span = (float)node_span;
+  for (int q = 0; q < CUBE_QMAX; ++q)
+    for (int d = 0; d < CUBE_QMAX; ++d) a.coef[q][d] = (q < Q && d < Q) ? basis_coef_h[q * Q + d] : 0.f;
+  a.N = N_out; a.C = C_out; a.MLd = MLd_out; a.MB = MB_out; a.jrange = reinterpret_cast<int2*>(jrange_out);
+  hipLaunchKernelGGL(band_basis_moments_kernel, dim3(nB), dim3(256), 0, (hipStream_t)stream, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+struct CubeArgs {
+  int nB, Q, nEnd, nMix;
+  long long nPix;
+  const double* centre;
+  const double* sigma;
+  float node_span;
+  float s_node[CUBE_QMAX];
+  const float *N, *C, *ALd, *AB;  // ALd [nB][nEnd], AB [Q][nB][nEnd]
+  const int* kidx;                // [nPix][nMix]
+  const float* frac;              // [nPix][nMix]
+  const double* Tpix;             // [nPix]
+  float* cube;                    // [nB][nPix]
+};
+
+// lanes <-> pixels (coalesced along the pixel axis of the cube), one band per blockIdx.y
+__global__ __launch_bounds__(256) void pixel_cube_kernel(CubeArgs a) {
+  const int b = blockIdx.y;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.nPix) return;
+  const double c = a.centre[b], Rn = (double)a.node_span * a.sigma[b];
+  const double c2l2e_over_T = 100.0 * RT_C2 * 1.4426950408889634 / a.Tpix[p];
+  float Bq[CUBE_QMAX];
+#pragma unroll
+  for (int q = 0; q < CUBE_QMAX; ++q) {
+    if (q < a.Q) {
+      const double x = c + Rn * (double)a.s_node[q];
+      const double x100 = x * 100.0;
+      Bq[q] = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, c2l2e_over_T);
+    } else {
+      Bq[q] = 0.f;
+    }
+  }
+  float acc = a.C[b];
+  for (int m = 0; m < a.nMix; ++m) {
+    const int k = a.kidx[p * a.nMix + m];
+    float t = -a.ALd[(size_t)b * a.nEnd + k];
+#pragma unroll
+    for (int q = 0; q < CUBE_QMAX; ++q)
+      if (q < a.Q) t = fmaf(Bq[q], a.AB[((size_t)q * a.nB + b) * a.nEnd + k], t);
+    acc = fmaf(a.frac[p * a.nMix + m], t, acc);
+  }
+  a.cube[(size_t)b * a.nPix + p] = acc / a.N[b];
+}
+
+extern "C" int rtx_pixel_cube(int nB, int Q, const double* centre, const double* sigma, double node_span, const float* s_node_h,
+                              const float* N, const float* C, const float* ALd, const float* AB, int nEnd, int64_t nPix,
+                              int nMix, const int32_t* kidx, const float* frac, const double* Tpix, float* cube, void* stream) {
+  if (Q < 1 || Q > CUBE_QMAX) RTX_FAIL("Q=%d outside [1,%d]", Q, CUBE_QMAX);
+  if (nB < 0 || nPix < 0 || nEnd < 1 || nMix < 1) RTX_FAIL("bad size");
+  if (nB == 0 || nPix == 0) return 0;
+  if (!centre || !sigma || !s_node_h || !N || !C || !ALd || !AB || !kidx || !frac || !Tpix || !cube) RTX_FAIL("a required pointer is NULL");
+  CubeArgs a;
+  a.nB = nB; a.Q = Q; a.nEnd = nEnd; a.nMix = nMix; a.nPix = nPix; a.centre = centre; a.sigma = sigma; a.node_span = (float)node_span;
+  for (int q = 0; q < CUBE_QMAX; ++q) a.s_node[q] = q < Q ? s_node_h[q] : 0.f;
+  a.N = N; a.C = C; a.ALd = ALd; a.AB = AB; a.kidx = kidx; a.frac = frac; a.Tpix = Tpix; a.cube = cube;
+  hipLaunchKernelGGL(pixel_cube_kernel, dim3((unsigned)((nPix + 255) / 256), nB), dim3(256), 0, (hipStream_t)stream, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }

@@ -85,3 +85,31 @@ def compute_TUD_sharded(Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, PLs, MFs_VAL,
 
     full = sharded_tud(compute_local, line_table, Xmin, Xmax, n_total, reach, group)
     return np.linspace(Xmin, Xmax, n_total), full[0], full[1], full[2]
+
+
+def all_gather_rows(local, n_rows_total, group=None):
+    """local: [n_loc][M] tensor holding this rank's shard_bounds() slice of the first axis.
+    Returns [n_rows_total][M] on every rank (one all_gather_into_tensor of a padded block)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local[:n_rows_total]
+    rank = dist.get_rank(group)
+    _, n_loc, per = shard_bounds(n_rows_total, world, rank)
+    assert local.shape[0] == n_loc, (local.shape, n_loc)
+    M = local.shape[1]
+    send = local if n_loc == per else torch.cat([local, local.new_zeros((per - n_loc, M))])
+    recv = torch.empty((world * per * M,), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send.contiguous().view(-1), group=group)
+    return recv.view(world * per, M)[:n_rows_total]
+
+
+def hsi_cube_sharded(compute_bands, n_bands_total, group=None):
+    """Config C5 across GPUs: the cube is cut along the BAND axis (a band's triangle only needs the
+    wavenumbers under it, so a band shard is a wavenumber shard with a ~3 % halo that is recomputed, not
+    exchanged). `compute_bands(b0, b1) -> [b1-b0][nPix]` tensor, e.g.
+        lambda b0, b1: sensor.hsi_cube(grid, tau, La, Ld, Xk, E, kidx, frac, T, band_slice=(b0, b1))[1]
+    One all-gather assembles the [n_bands_total][nPix] cube on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    b0, nb, _ = shard_bounds(n_bands_total, world, rank)
+    return all_gather_rows(compute_bands(b0, b0 + nb), n_bands_total, group)

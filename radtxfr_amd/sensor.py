@@ -17,7 +17,8 @@ from .radiative_transfer import _MAKO_UM
 def interp_knots(grid, Xk, F):
     """np.interp(grid, Xk, F[:, s]) for every column: F [nk][nS] float32 device -> [grid.n][nS] float32."""
     lib = _lib.load()
-    assert F.dtype == torch.float32 and F.is_cuda and F.is_contiguous() and F.dim() == 2
+    assert F.dtype == torch.float32 and F.is_cuda and F.dim() == 2
+    F = F.contiguous()
     Xk_d = torch.as_tensor(np.asarray(Xk, dtype=np.float64), device=F.device).contiguous()
     out = torch.empty((grid.n, F.shape[1]), dtype=torch.float32, device=F.device)
     _lib.check(lib.rtx_interp_knots(grid.byref(), None, grid.n, C.c_void_p(Xk_d.data_ptr()), Xk_d.numel(),
@@ -49,7 +50,8 @@ def band_radiance_fused(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, k
         X_out = np.sort(10000.0 / _MAKO_UM)
         centre, sigma = X_out, np.abs(np.gradient(X_out))
     nB, nk, nE = X_out.size, len(Xk), emis_knots.shape[1]
-    assert emis_knots.dtype == torch.float32 and emis_knots.is_contiguous() and emis_knots.shape[0] == nk
+    assert emis_knots.dtype == torch.float32 and emis_knots.shape[0] == nk
+    emis_knots = emis_knots.contiguous()
     Xk_d = torch.as_tensor(np.asarray(Xk, dtype=np.float64), device=dev)
     c_d, s_d = torch.as_tensor(centre, device=dev), torch.as_tensor(sigma, device=dev)
     N = torch.empty(nB, dtype=torch.float32, device=dev)
@@ -63,6 +65,59 @@ def band_radiance_fused(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, k
                                     p(N), p(Cb), p(M), p(jr), st))
     _lib.check(lib.rtx_band_mix(p(N), p(Cb), p(M), p(jr), nB, nk, p(emis_knots), nE, p(out), st))
     return X_out, out
+
+
+def chebyshev_lagrange(Q):
+    """Chebyshev nodes s_q on (-1,1) and the monomial coefficients coef[q][d] of their Lagrange basis."""
+    s = np.cos((2 * np.arange(Q) + 1) * np.pi / (2 * Q))
+    coef = np.zeros((Q, Q))
+    for q in range(Q):
+        others = np.delete(s, q)
+        poly = np.poly(others) / np.prod(s[q] - others)  # highest power first
+        coef[q] = poly[::-1]
+    return s, coef
+
+
+def hsi_cube(grid, tau, La, Ld, Xk, endmembers, kidx, frac, Tpix, resFactor=2, band_slice=None, Q=5):
+    """Config C5: band radiances of an HSI cube whose pixels each have an emissivity mixture and a surface
+    temperature of their own (LWIR_HSI_Generator.py:151-167), from monochromatic tau/La/Ld through the
+    triangle ILS (rt.ILS_MAKO with resFactor).
+
+    endmembers [nk][nEnd] float32 device (knot spectra), kidx [nPix][nMix] int32, frac [nPix][nMix] float32,
+    Tpix [nPix] float64 -- device tensors. band_slice: (b0, b1) to compute only a band-aligned shard.
+    Returns (X_out [nB] NumPy, cube [nB][nPix] float32 device)."""
+    lib = _lib.load()
+    dev = tau.device
+    X_out, centre, sigma = mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
+    if band_slice is not None:
+        X_out, centre, sigma = X_out[band_slice[0]:band_slice[1]], centre[band_slice[0]:band_slice[1]], sigma[band_slice[0]:band_slice[1]]
+    nB, nk, nEnd = X_out.size, len(Xk), endmembers.shape[1]
+    nPix, nMix = kidx.shape
+    assert endmembers.dtype == torch.float32 and endmembers.shape[0] == nk
+    endmembers = endmembers.contiguous()
+    assert kidx.dtype == torch.int32 and frac.dtype == torch.float32 and Tpix.dtype == torch.float64
+    s_nodes, coef = chebyshev_lagrange(Q)
+    coef32 = np.ascontiguousarray(coef, dtype=np.float32)
+    sn32 = np.ascontiguousarray(s_nodes, dtype=np.float32)
+    Xk_d = torch.as_tensor(np.asarray(Xk, dtype=np.float64), device=dev)
+    c_d, s_d = torch.as_tensor(centre, device=dev), torch.as_tensor(sigma, device=dev)
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    N, Cb, MLd, MB = f32(nB), f32(nB), f32(nB, nk), f32(Q, nB, nk)
+    jr = torch.empty((nB, 2), dtype=torch.int32, device=dev)
+    ALd, AB = f32(nB, nEnd), f32(Q, nB, nEnd)
+    cube = f32(nB, nPix)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if nB == 0:
+        return X_out, cube
+    _lib.check(lib.rtx_band_basis_moments(0, grid.byref(), p(tau), p(La), p(Ld), p(Xk_d), nk, nB, p(c_d), p(s_d), Q,
+                                          coef32.ctypes.data_as(C.c_void_p), 1.0, p(N), p(Cb), p(MLd), p(MB), p(jr), st))
+    _lib.check(lib.rtx_band_mix(None, None, p(MLd), p(jr), nB, nk, p(endmembers), nEnd, p(ALd), st))
+    for q in range(Q):
+        _lib.check(lib.rtx_band_mix(None, None, p(MB[q]), p(jr), nB, nk, p(endmembers), nEnd, p(AB[q]), st))
+    _lib.check(lib.rtx_pixel_cube(nB, Q, p(c_d), p(s_d), 1.0, sn32.ctypes.data_as(C.c_void_p), p(N), p(Cb), p(ALd), p(AB), nEnd,
+                                  nPix, nMix, p(kidx.contiguous()), p(frac.contiguous()), p(Tpix.contiguous()), p(cube), st))
+    return X_out, cube
 
 
 def band_radiance(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, keep_hires=False):

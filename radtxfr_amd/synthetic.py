@@ -77,3 +77,17 @@ def synth_emissivities(seed=SEED_C4, n_emis=2000):
     e = 0.85 + 0.1 * np.sin(2 * np.pi * X_e[:, None] / P[None, :] + phi[None, :]) \
         + 0.02 * rng.standard_normal((X_e.size, n_emis))
     return X_e, np.clip(e, 1e-4, 1 - 1e-4)
+
+
+def synth_scene(seed=SEED_C5, n_pix=256 * 256, n_end=6, n_mix=2, Ts=287.87, dT=3.0, n_emis_db=2000):
+    """C5 scene (after LWIR_HSI_Generator.py:147-162): n_end endmembers drawn from the C4 emissivity
+    set, every pixel a mixture of n_mix of them with normalised uniform fractions and a surface temperature
+    Ts + dT*N(0,1). Returns dict(end_idx [n_end] into the C4 set, kidx [n_pix][n_mix] in [0,n_end),
+    frac [n_pix][n_mix], T [n_pix])."""
+    rng = np.random.default_rng(seed)
+    end_idx = rng.integers(0, n_emis_db, n_end)
+    kidx = rng.integers(0, n_end, (n_pix, n_mix))
+    frac = rng.random((n_pix, n_mix))
+    frac /= frac.sum(axis=1)[:, None]
+    T = Ts + dT * rng.standard_normal(n_pix)
+    return {"end_idx": end_idx, "kidx": kidx.astype(np.int32), "frac": frac, "T": T}

@@ -53,6 +53,24 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _cube_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(7 * 5, dtype=torch.float32).reshape(7, 5)  # 7 "bands" over 2 ranks: ragged
+        got = rdist.hsi_cube_sharded(lambda b0, b1: full[b0:b1].clone(), 7)
+        np.save(os.path.join(out_dir, f"c{rank}.npy"), got.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_band_sharded_cube(tmp_path):
+    mp.spawn(_cube_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = np.arange(35, dtype=np.float32).reshape(7, 5)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"c{r}.npy"), want)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

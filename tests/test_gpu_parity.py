@@ -357,6 +357,38 @@ def test_c4_band_radiance_vs_oracle(rt):
     assert rel_err(e2, r2) <= 1e-6
 
 
+# ----------------------------------------------------------------------------- C5: fused HSI cube
+def test_c5_hsi_cube_vs_oracle(rt):
+    """Config C5 at oracle size: 96 pixels, each a 2-of-6 endmember mixture with its own surface temperature
+    (LWIR_HSI_Generator.py:151-167), monochromatic radiance -> rt.ILS_MAKO(resFactor=2). The device path never
+    forms a per-pixel spectrum; the oracle does exactly that."""
+    import torch
+    from radtxfr_amd import engine, sensor
+    Xe, em = synthetic.synth_emissivities(n_emis=2000)
+    sc = synthetic.synth_scene(n_pix=96)
+    E = em[:, sc["end_idx"]]  # [nk][6]
+    grid = engine.Grid(760.0, 1320.0, 56000)
+    X = grid.axis()
+    tau = 0.5 + 0.45 * np.sin(X / 13.0)
+    La = 2.0 + np.cos(X / 29.0)
+    Ld = 4.0 + 2.0 * np.sin(X / 7.0)
+    dev = torch.device("cuda")
+    f32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32), device=dev)
+    xo, cube = sensor.hsi_cube(grid, f32(tau), f32(La), f32(Ld), Xe, f32(E), torch.as_tensor(sc["kidx"], device=dev),
+                               f32(sc["frac"]), torch.as_tensor(sc["T"], device=dev), resFactor=2)
+    E_hi = np.stack([np.interp(X, Xe, E[:, k]) for k in range(E.shape[1])], axis=1)      # [nX][6]
+    em_p = np.einsum("pm,xpm->xp", sc["frac"], E_hi[:, sc["kidx"]])                       # [nX][nPix]
+    B = ref.planckian(X, sc["T"])                                                          # [nX][nPix]
+    L = tau[:, None] * (em_p * B + (1 - em_p) * Ld[:, None]) + La[:, None]
+    xr, Lr = ref.ILS_MAKO(X, L, resFactor=2)
+    assert np.array_equal(xo, xr) and cube.shape == Lr.shape == (xr.size, 96)
+    assert rel_err(cube.cpu().numpy(), Lr) <= TOL_L
+    # a band-aligned shard computes the same numbers as the same rows of the full cube
+    _, part = sensor.hsi_cube(grid, f32(tau), f32(La), f32(Ld), Xe, f32(E), torch.as_tensor(sc["kidx"], device=dev),
+                              f32(sc["frac"]), torch.as_tensor(sc["T"], device=dev), resFactor=2, band_slice=(40, 97))
+    assert torch.equal(part, cube[40:97])
+
+
 # --------------------------------------------------------- size-independent properties at full size
 def test_full_c3_width_properties():
     """5.5 M-point C3 grid x 32 layers at full size: properties that need no oracle run.
