@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, gather staged through the host); never a measurement")
     args = ap.parse_args()
 
     import torch
@@ -71,10 +73,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    local = local % torch.cuda.device_count() if args.backend == "gloo" else local
     torch.cuda.set_device(local)
     _lib.load()
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     # ---- inputs, resident in HBM before timing --------------------------------------------------
     full = synthetic.synth_line_table(synthetic.SEED_C3, N_LINES, 475.0, 6025.0)
@@ -113,7 +119,12 @@ def main():
             ev[2].record()
         if world > 1:
             packed[0, :n_loc], packed[1, :n_loc], packed[2, :n_loc] = tau[0], Lu[0], Ld
-            dist.all_gather_into_tensor(gathered, packed.view(-1))
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, packed.view(-1))
+            else:
+                g_cpu = torch.empty(gathered.shape, dtype=gathered.dtype)
+                dist.all_gather_into_tensor(g_cpu, packed.view(-1).cpu())
+                gathered.copy_(g_cpu)
         return tau, Lu, Ld
 
     def sync():
@@ -130,7 +141,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

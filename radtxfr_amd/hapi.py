@@ -28,7 +28,8 @@ DefaultOmegaWingHW = 50.0        # misc/hapi.py:10218
 
 # name -> {'header': {'number_of_rows': n, ...}, 'data': {column: list-or-array}}
 LOCAL_TABLE_CACHE = {}
-_DEVICE_TABLES = {}
+_DEVICE_TABLES = {}   # tuple(table names) -> (signature, engine.LineTable); least recently used entries are closed
+_DEVICE_TABLES_MAX = 8
 
 
 def storage2cache_from_columns(TableName, columns):
@@ -44,6 +45,7 @@ def _device_table(names):
     sig = tuple((id(LOCAL_TABLE_CACHE[n]["data"].get("nu")), LOCAL_TABLE_CACHE[n]["header"]["number_of_rows"]) for n in names)
     hit = _DEVICE_TABLES.get(key)
     if hit is not None and hit[0] == sig:
+        _DEVICE_TABLES[key] = _DEVICE_TABLES.pop(key)  # mark most recently used
         return hit[1]
     cols = {}
     keys = None
@@ -64,7 +66,14 @@ def _device_table(names):
     if hit is not None:
         hit[1].close()
     tbl = engine.LineTable(merged)
+    _DEVICE_TABLES.pop(key, None)
     _DEVICE_TABLES[key] = (sig, tbl)
+    while len(_DEVICE_TABLES) > _DEVICE_TABLES_MAX:  # bound the device memory held for callers' tables
+        old_key = next(iter(_DEVICE_TABLES))
+        _DEVICE_TABLES.pop(old_key)[1].close()
+        for n in old_key:
+            if n.startswith("__dict_"):
+                LOCAL_TABLE_CACHE.pop(n, None)
     return tbl
 
 

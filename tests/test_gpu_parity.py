@@ -315,6 +315,37 @@ def test_ils_many_spectra_and_edges(rt):
     assert rel_err(yo[ok], yr[ok]) <= TOL_L
 
 
+# ------------------------------------------------------------ C1 / C2 of BASELINE.json at full size
+def test_c1_planck_beer_lambert(rt):
+    """Config C1: X = linspace(700,1400,700), surface at 287.87 K with eps = 1, one layer at 287.87 K with
+    OD = 0.3(1+sin(nu/20)); L = tau B(Ts) + (1-tau) B(T), through the shim's planckian + apparent radiance."""
+    X = np.linspace(700.0, 1400.0, 700)
+    OD = 0.3 * (1.0 + np.sin(X / 20.0))
+    tau = np.exp(-OD)
+    Bl = rt.planckian(X, 287.87)
+    La = (1.0 - tau) * Bl
+    L = rt.compute_LWIR_apparent_radiance(X, np.ones((X.size, 1)), np.array([287.87]), tau[:, None], La[:, None], np.zeros((X.size, 1)))
+    want = tau * ref.planckian(X, 287.87) + (1.0 - tau) * ref.planckian(X, 287.87)
+    assert L.shape == (700, 1, 1) and rel_err(L[:, 0, 0], want) <= TOL_L
+
+
+def test_c2_voigt_full_config(hapi):
+    """Config C2: 20 000-line H2O+CO2 table (seed 20261004), 700-1400 cm^-1 @ 0.01 (70 000 points),
+    one layer at the surface state; the whole spectrum against the oracle."""
+    tbl = synthetic.synth_line_table(synthetic.SEED_C2, 20000, 675.0, 1425.0)
+    hapi.storage2cache_from_columns("c2", tbl)
+    grid = np.linspace(700.0, 1400.0, 70000)
+    T, p = 287.87, 100697.30225 / 101325.0
+    om, xs = hapi.absorptionCoefficient_Voigt(SourceTables="c2", Environment={"T": T, "p": p}, OmegaGrid=grid)
+    _, xr = ref.absorptionCoefficient_Voigt(tbl, T=T, p=p, OmegaGrid=grid)
+    assert np.array_equal(om, grid) and rel_err(xs, xr) <= TOL_L
+    # per-molecule components with HITRAN_units=False (what compute_OD sums), CO2 only
+    _, xs2 = hapi.absorptionCoefficient_Voigt(Components=[(2, 1), (2, 2)], SourceTables="c2", Environment={"T": T, "p": p},
+                                              OmegaGrid=grid, HITRAN_units=False)
+    _, xr2 = ref.absorptionCoefficient_Voigt(tbl, Components=[(2, 1), (2, 2)], T=T, p=p, OmegaGrid=grid, HITRAN_units=False)
+    assert rel_err(xs2, xr2) <= TOL_L
+
+
 # ------------------------------------------------ C4: knots -> grid -> at-sensor radiance -> MAKO bands
 def test_c4_band_radiance_vs_oracle(rt):
     """Config C4 at a size the oracle finishes in seconds: 40 emissivities on the ASTER-DB knots,
