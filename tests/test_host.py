@@ -142,3 +142,31 @@ def test_layer_weights_follow_the_od_contract():
     np.testing.assert_array_equal(w[0], w[1])
     np.testing.assert_allclose(w[2], n * MF[:, 1] * 1e-6 * PL * 1e5, rtol=1e-15)
     assert np.all(w[3] == 0) and np.allclose(p_atm, [1.0, 50000.0 / 101325.0])
+
+
+def test_hitran_par_roundtrip(tmp_path):
+    """the 160-column .par layout (misc/hapi.py:468-559) written and parsed back; synthetic tables
+    are already rounded to .par precision, so the round trip is exact."""
+    from radtxfr_amd import hapi, hitran_par, synthetic
+    tbl = synthetic.synth_line_table(7, 500, 600.0, 1400.0)
+    tbl["local_iso_id"][:3] = [10, 11, 12]  # '0', 'A', 'B' codes
+    p = tmp_path / "t.par"
+    hitran_par.write_par(str(p), tbl)
+    lines = open(p).read().splitlines()
+    assert len(lines) == 500 and all(len(ln) == 160 for ln in lines)
+    got = hitran_par.storage2cache("t", str(p))
+    for k in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air"):
+        assert np.array_equal(got[k], tbl[k]), k
+    assert hapi.LOCAL_TABLE_CACHE["t"]["header"]["number_of_rows"] == 500
+    # a HITRAN-style record typed by hand (columns per HITRAN_FORMAT_160)
+    rec = " 2" + "1" + "  667.661431" + " 1.152E-19" + " 1.518E+00" + ".0720" + "0.094" + "    3.9032" + "0.75" + "-.000870"
+    assert len(rec) == 67
+    q = tmp_path / "one.par"
+    q.write_text(rec.ljust(160) + "\n")
+    one = hitran_par.read_par(str(q))
+    assert (one["molec_id"][0], one["local_iso_id"][0]) == (2, 1)
+    assert one["nu"][0] == 667.661431 and one["sw"][0] == 1.152e-19 and one["gamma_air"][0] == 0.072
+    assert one["gamma_self"][0] == 0.094 and one["elower"][0] == 3.9032 and one["n_air"][0] == 0.75 and one["delta_air"][0] == -0.00087
+    with pytest.raises(ValueError):
+        q.write_text("too short\n")
+        hitran_par.read_par(str(q))
