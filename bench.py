@@ -34,12 +34,12 @@ N_LAYERS = 32
 
 
 def cpu_baseline(full_table, atm, seconds_hint=15.0):
-    """Oracle (kind 'port') on a bounded sample of the same workload: a 40 cm^-1 window of the C3 grid
+    """Oracle (kind 'port') on a bounded sample of the same workload: a 160 cm^-1 window of the C3 grid
     (all 32 layers, the lines that can reach it), single process."""
     from oracle import cpu_ref
     from radtxfr_amd import synthetic
     X = np.linspace(500.0, 6000.0, N_WAVENUMBERS)
-    i0, n = 2500000, 40000
+    i0, n = 2500000, 160000
     Xw = X[i0:i0 + n]
     sub = synthetic.subset_table(full_table, Xw[0] - 12.0, Xw[-1] + 12.0)
     t0 = time.perf_counter()
