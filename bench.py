@@ -103,10 +103,14 @@ def main():
     qratio, mass = engine.species_factors(lines.species, T)
     dev = torch.device("cuda", local)
     OD = torch.empty((N_LAYERS, n_loc), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * 3 * per,), dtype=torch.float32, device=dev) if world > 1 else None
-    packed = torch.zeros((3, per), dtype=torch.float32, device=dev) if world > 1 else None
+    # N > 1: the TUD kernel writes straight into the packed [3][per] block that is all-gathered; two blocks so the
+    # RCCL all-gather of step k overlaps the kernels of step k+1 (separate stream, async_op)
+    gathered = [torch.empty((world * 3 * per,), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    packed = [torch.zeros((3, per), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t_voigt, t_tud = [], []
+    counter = [0]
 
     def step(record=False):
         if record:
@@ -114,20 +118,35 @@ def main():
         engine.voigt_sum(lines, grid, T, p_atm, w, out_f32=OD, qratio=qratio, mass=mass)
         if record:
             ev[1].record()
-        tau, Lu, Ld, _ = engine.tud(OD, grid, T, Z)
+        if world == 1:
+            tau, Lu, Ld, _ = engine.tud(OD, grid, T, Z)
+        else:
+            b = counter[0] & 1
+            counter[0] += 1
+            if pending[b] is not None:
+                pending[b].wait()  # this block's previous all-gather must be done before it is overwritten
+                pending[b] = None
+            pk = packed[b]
+            tau, Lu, Ld, _ = engine.tud(OD, grid, T, Z, out=(pk[0:1], pk[1:2], pk[2]))
         if record:
             ev[2].record()
         if world > 1:
-            packed[0, :n_loc], packed[1, :n_loc], packed[2, :n_loc] = tau[0], Lu[0], Ld
             if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, packed.view(-1))
+                pending[b] = dist.all_gather_into_tensor(gathered[b], pk.view(-1), async_op=True)
             else:
-                g_cpu = torch.empty(gathered.shape, dtype=gathered.dtype)
-                dist.all_gather_into_tensor(g_cpu, packed.view(-1).cpu())
-                gathered.copy_(g_cpu)
+                g_cpu = torch.empty(gathered[b].shape, dtype=gathered[b].dtype)
+                dist.all_gather_into_tensor(g_cpu, pk.view(-1).cpu())
+                gathered[b].copy_(g_cpu)
         return tau, Lu, Ld
 
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
     def sync():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

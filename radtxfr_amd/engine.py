@@ -244,8 +244,10 @@ def optical_depths(lines, grid, T, P_pa, PL_km, MF_VAL, MF_ID, out=None):
     return out
 
 
-def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=False, per_angle=False):
-    """tau[nAlt*nMu][n], Lu[nAlt*nMu][n], Ld[n] float32 device tensors from OD[nL][n] (rtx_tud)."""
+def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=False, per_angle=False, out=None):
+    """tau[nAlt*nMu][n], Lu[nAlt*nMu][n], Ld[n] float32 device tensors from OD[nL][n] (rtx_tud).
+    out=(tau, Lu, Ld): write into caller-owned tensors (tau/Lu [nAlt*nMu][>=n] with a common row stride),
+    e.g. the rows of the packed block a wavenumber shard all-gathers."""
     lib = _lib.load()
     T = np.atleast_1d(np.asarray(T, dtype=np.float64))
     Z = np.atleast_1d(np.asarray(Z, dtype=np.float64))
@@ -257,15 +259,22 @@ def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=Fals
     mask = np.ascontiguousarray(np.stack([(Z <= zs) for zs in Z_s]).astype(np.uint8))
     n_down = int(mask[-1].sum())  # quirk 3: nL is overwritten by the LAST altitude's count (:353, :370)
     dev = OD.device
-    tau = torch.empty((Z_s.size * mu_s.size, grid.n), dtype=torch.float32, device=dev)
-    Lu = torch.empty_like(tau)
-    Ld = torch.empty((grid.n,), dtype=torch.float32, device=dev)
+    if out is None:
+        tau = torch.empty((Z_s.size * mu_s.size, grid.n), dtype=torch.float32, device=dev)
+        Lu = torch.empty_like(tau)
+        Ld = torch.empty((grid.n,), dtype=torch.float32, device=dev)
+    else:
+        tau, Lu, Ld = out
+        for t in (tau, Lu):
+            assert t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and t.shape[0] == Z_s.size * mu_s.size
+            assert t.shape[1] >= grid.n and t.stride(1) == 1 and t.stride(0) == tau.stride(0)
+        assert Ld.dtype == torch.float32 and Ld.is_cuda and Ld.numel() >= grid.n and Ld.stride(0) == 1
     Ld_ang = torch.empty((int(N_angle), grid.n), dtype=torch.float32, device=dev) if per_angle else None
     T_h, T_p = _h(T)
     mu_h, mu_p = _h(mu_s)
     _lib.check(lib.rtx_tud(_ptr(OD), OD.stride(0), grid.byref(), nL, T_p, Z_s.size, mask.ctypes.data_as(C.c_void_p),
                            mu_s.size, mu_p, n_down, int(N_angle), int(bool(returnOD)), _ptr(tau), _ptr(Lu), _ptr(Ld),
-                           _ptr(Ld_ang), grid.n, _stream_ptr()))
+                           _ptr(Ld_ang), tau.stride(0) if tau.shape[0] > 1 else max(tau.shape[1], grid.n), _stream_ptr()))
     if per_angle:
         return tau, Lu, Ld, (Z_s.size, mu_s.size), Ld_ang
     return tau, Lu, Ld, (Z_s.size, mu_s.size)
