@@ -19,50 +19,12 @@
 // is evaluated in fp32 from a grid-relative argument (integer index difference times step*cte plus
 // a sub-grid residual), which keeps (nu - nu0) exact to ~1e-7 relative; the region test and the
 // Weideman-24 branch use the fp64 record (fp64 polynomial when y<1, where fp32 loses Re w).
+#include <stdlib.h>
+#include <string.h>
+
 #include "rtx_common.h"
 
-#include "w24_coeffs.inc"
-#define INV_SQRT_PI 0.56418958354775628
-
-// Re w(x+iy) by Weideman's rational expansion (misc/hapi.py:9812-9827), real arithmetic:
-//   Z = (L + i z)/(L - i z),  w = 2 p(Z)/(L - i z)^2 + (1/sqrt(pi))/(L - i z),  p = 24-term polynomial.
-// p is evaluated as pe(Z^2) + Z*po(Z^2): two independent 12-step Horner chains instead of one 24-step
-// chain, so a single wave keeps 4 FMAs in flight (the serial chain stalled the band rows).
-template <typename F>
-__device__ __forceinline__ F weideman_re(F x, F y) {
-  const F L = (F)W24_L;
-  constexpr const F* coef = []() constexpr -> const F* { if constexpr (sizeof(F) == 4) return (const F*)W24F; else return (const F*)W24D; }();
-  // d = L - i z = (L+y) - i x ;  n = L + i z = (L-y) + i x ;  Z = n/d = n*conj(d)/|d|^2
-  const F dr = L + y, nr = L - y;
-  const F dd = fma(dr, dr, x * x);
-  F inv;
-  if constexpr (sizeof(F) == 4) {
-    inv = __builtin_amdgcn_rcpf(dd);
-    inv = fma(fma(-dd, inv, (F)1), inv, inv);  // one Newton step: < 1 ulp
-  } else {
-    inv = (F)1 / dd;
-  }
-  const F Zr = fma(nr, dr, -(x * x)) * inv;   // Re[(nr + i x)(dr + i x)]
-  const F Zi = (x * (nr + dr)) * inv;         // Im[...] = x*dr + nr*x
-  const F Wr = fma(Zr, Zr, -(Zi * Zi)), Wi = (F)2 * Zr * Zi;  // W = Z^2
-  // coef[] is in polyval order: p = sum_k coef[k] Z^(23-k); odd powers <-> even k
-  F or_ = coef[0], oi = (F)0;  // po: coefficients of Z^23, Z^21, ... (k = 0, 2, ...)
-  F er = coef[1], ei = (F)0;   // pe: coefficients of Z^22, Z^20, ... (k = 1, 3, ...)
-#pragma unroll
-  for (int k = 2; k < 24; k += 2) {
-    const F t0 = fma(or_, Wr, fma(-oi, Wi, coef[k]));
-    const F t1 = fma(or_, Wi, oi * Wr);
-    const F t2 = fma(er, Wr, fma(-ei, Wi, coef[k + 1]));
-    const F t3 = fma(er, Wi, ei * Wr);
-    or_ = t0; oi = t1; er = t2; ei = t3;
-  }
-  const F pr = fma(or_, Zr, fma(-oi, Zi, er));  // p = pe + Z*po
-  const F pi = fma(or_, Zi, fma(oi, Zr, ei));
-  // 1/d = conj(d)*inv = (dr + i x)*inv ; w = 2 p /d^2 + (1/sqrt(pi))/d
-  const F ir = dr * inv, ii = x * inv;
-  const F i2r = fma(ir, ir, -(ii * ii)), i2i = (F)2 * ir * ii;
-  return fma((F)2, fma(pr, i2r, -(pi * i2i)), (F)INV_SQRT_PI * ir);
-}
+#include "rtx_voigt_math.h"
 
 struct VsArgs {
   const LineRec* rec;      // [n_layers][n_lines]
@@ -111,15 +73,6 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
   }
   a.ranges[(size_t)k * a.n_tiles + t] = make_int2((int)l0, (int)lo);
 }
-
-// One far-wing evaluation: Re[(1/sqrt(pi)) t/(1/2+t^2)], t = y - i x  (hum1_wei, :9834-9835) times the
-// line strength, as  (xx*Ay + Ay0) / ((xx + b1)*xx + b0)  with per-line constants from the fp64 prologue;
-// x = u*a + c with u = i - i0 an exact integer-valued float.  7 full-rate VALU ops + 1 v_rcp_f32.
-#define RTX_FARWING(u_, q_, num_, rden_)                      \
-  const float x_ = fmaf((u_), (q_).a, (q_).c);                \
-  const float xx_ = x_ * x_;                                  \
-  float num_ = fmaf(xx_, (q_).Ay, (q_).Ay0);                  \
-  float rden_ = __builtin_amdgcn_rcpf(fmaf(xx_ + (q_).b1, xx_, (q_).b0))
 
 // CORE64 = false: the main pass. Far wing everywhere, fp32 Weideman inside the bands of lines with y >= 1.
 // CORE64 = true : a second, usually empty, pass that ADDS the band points of lines with y < 1
@@ -325,7 +278,34 @@ __global__ __launch_bounds__(256, RTX_VOIGT_WAVES) void voigt_sum_kernel(VsArgs 
 #define RTX_VOIGT_P 4  // measured on MI355X, C3 workload: P=2 12.3 ms, P=4 6.6 ms, P=8 7.3 ms, P=16 14 ms
 #endif
 
-extern "C" int rtx_voigt_tile_points(void) { return 4 * 64 * RTX_VOIGT_P; }
+extern "C" int rtx_voigt_scatter_tile_points(void);
+// capacity granularity of rtx_prep_create: the smaller of the two kernels' tiles
+extern "C" int rtx_voigt_tile_points(void) {
+  const int g = 4 * 64 * RTX_VOIGT_P, s = rtx_voigt_scatter_tile_points();
+  return g < s ? g : s;
+}
+
+// rtx_voigt_scatter.hip
+int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64, int64_t ld,
+                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t));
+
+static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_layers, int n_tiles, int tile, hipStream_t st) {
+  RangeArgs ra;
+  ra.ic = P->ic; ra.maxhw = P->maxhw; ra.n_lines = P->n_lines; ra.n_tiles = n_tiles; ra.tile = tile;
+  ra.n_layers = n_layers; ra.n = grid->n; ra.ranges = P->ranges;
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles + 255) / 256, n_layers), dim3(256), 0, st, ra);
+}
+
+// RADTXFR_VOIGT_KERNEL=gather selects the register-accumulator kernel of this file (bit-identical across
+// wavenumber shards); the default is the scatter kernel (rtx_voigt_scatter.hip), which is faster.
+static bool use_gather_kernel() {
+  static int cached = -1;
+  if (cached < 0) {
+    const char* e = getenv("RADTXFR_VOIGT_KERNEL");
+    cached = (e && strcmp(e, "gather") == 0) ? 1 : 0;
+  }
+  return cached == 1;
+}
 
 extern "C" int rtx_voigt_sum(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64,
                              int64_t ld, void* stream) {
@@ -345,10 +325,8 @@ extern "C" int rtx_voigt_sum(const rtx_prep* P, const rtx_grid* grid, int n_laye
     if (out_f64) RTX_HIP(hipMemset2DAsync(out_f64, ld * sizeof(double), 0, grid->n * sizeof(double), n_layers, st));
     return 0;
   }
-  RangeArgs ra;
-  ra.ic = P->ic; ra.maxhw = P->maxhw; ra.n_lines = P->n_lines; ra.n_tiles = n_tiles; ra.tile = TILE;
-  ra.n_layers = n_layers; ra.n = grid->n; ra.ranges = P->ranges;
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles + 255) / 256, n_layers), dim3(256), 0, st, ra);
+  if (!use_gather_kernel()) return rtx_voigt_sum_scatter(P, grid, n_layers, out_f32, out_f64, ld, st, launch_tile_ranges);
+  launch_tile_ranges(P, grid, n_layers, n_tiles, TILE, st);
   RTX_LAUNCH_CHECK();
   VsArgs a;
   a.rec = P->rec; a.rec64 = P->rec64; a.ranges = P->ranges; a.smally = P->smally; a.n_lines = P->n_lines;

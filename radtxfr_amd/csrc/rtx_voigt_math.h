@@ -1,0 +1,83 @@
+// Shared arithmetic of the two Voigt line-sum kernels (rtx_voigt.hip: gather, rtx_voigt_scatter.hip: scatter).
+#pragma once
+#include "rtx_common.h"
+#include "w24_coeffs.inc"
+#define INV_SQRT_PI 0.56418958354775628
+
+// Re w(x+iy) by Weideman's rational expansion (misc/hapi.py:9812-9827), real arithmetic:
+//   Z = (L + i z)/(L - i z),  w = 2 p(Z)/(L - i z)^2 + (1/sqrt(pi))/(L - i z),  p = 24-term polynomial.
+// p is evaluated as pe(Z^2) + Z*po(Z^2): two independent 12-step Horner chains instead of one 24-step
+// chain, so a single wave keeps 4 FMAs in flight (the serial chain stalled the band rows).
+template <typename F>
+__device__ __forceinline__ F weideman_re(F x, F y) {
+  const F L = (F)W24_L;
+  constexpr const F* coef = []() constexpr -> const F* { if constexpr (sizeof(F) == 4) return (const F*)W24F; else return (const F*)W24D; }();
+  // d = L - i z = (L+y) - i x ;  n = L + i z = (L-y) + i x ;  Z = n/d = n*conj(d)/|d|^2
+  const F dr = L + y, nr = L - y;
+  const F dd = fma(dr, dr, x * x);
+  F inv;
+  if constexpr (sizeof(F) == 4) {
+    inv = __builtin_amdgcn_rcpf(dd);
+    inv = fma(fma(-dd, inv, (F)1), inv, inv);  // one Newton step: < 1 ulp
+  } else {
+    inv = (F)1 / dd;
+  }
+  const F Zr = fma(nr, dr, -(x * x)) * inv;   // Re[(nr + i x)(dr + i x)]
+  const F Zi = (x * (nr + dr)) * inv;         // Im[...] = x*dr + nr*x
+  const F Wr = fma(Zr, Zr, -(Zi * Zi)), Wi = (F)2 * Zr * Zi;  // W = Z^2
+  // coef[] is in polyval order: p = sum_k coef[k] Z^(23-k); odd powers <-> even k
+  F or_ = coef[0], oi = (F)0;  // po: coefficients of Z^23, Z^21, ... (k = 0, 2, ...)
+  F er = coef[1], ei = (F)0;   // pe: coefficients of Z^22, Z^20, ... (k = 1, 3, ...)
+#pragma unroll
+  for (int k = 2; k < 24; k += 2) {
+    const F t0 = fma(or_, Wr, fma(-oi, Wi, coef[k]));
+    const F t1 = fma(or_, Wi, oi * Wr);
+    const F t2 = fma(er, Wr, fma(-ei, Wi, coef[k + 1]));
+    const F t3 = fma(er, Wi, ei * Wr);
+    or_ = t0; oi = t1; er = t2; ei = t3;
+  }
+  const F pr = fma(or_, Zr, fma(-oi, Zi, er));  // p = pe + Z*po
+  const F pi = fma(or_, Zi, fma(oi, Zr, ei));
+  // 1/d = conj(d)*inv = (dr + i x)*inv ; w = 2 p /d^2 + (1/sqrt(pi))/d
+  const F ir = dr * inv, ii = x * inv;
+  const F i2r = fma(ir, ir, -(ii * ii)), i2i = (F)2 * ir * ii;
+  return fma((F)2, fma(pr, i2r, -(pi * i2i)), (F)INV_SQRT_PI * ir);
+}
+
+// Re w(x+iy) for |z| >= 6 by the asymptotic series  w ~ (i/(sqrt(pi) z)) sum_k (2k-1)!! / (2 z^2)^k, k = 0..5.
+// Against the Weideman-24 value (what the reference computes inside |x|+y<15) the truncation error is < 6.5e-8
+// for y >= 6 (checked in fp64 over the whole band); evaluated in fp32 it is at rounding level (3e-7).
+__device__ __forceinline__ float asym6_re(float x, float y) {
+  const float r2 = fmaf(x, x, y * y);
+  float inv = __builtin_amdgcn_rcpf(r2);
+  inv = fmaf(fmaf(-r2, inv, 1.0f), inv, inv);
+  const float zr = x * inv, zi = -y * inv;                         // 1/z
+  const float ur = fmaf(zr, zr, -(zi * zi)), ui = 2.0f * zr * zi;  // 1/z^2
+  float pr = 945.0f / 32.0f, pi = 0.0f;
+  constexpr float c[5] = {105.0f / 16.0f, 15.0f / 8.0f, 0.75f, 0.5f, 1.0f};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const float tr = fmaf(pr, ur, fmaf(-pi, ui, c[k]));
+    const float ti = fmaf(pr, ui, pi * ur);
+    pr = tr;
+    pi = ti;
+  }
+  return -(float)INV_SQRT_PI * fmaf(zr, pi, zi * pr);  // Re[(i/sqrt(pi)) (1/z) p] = -(1/sqrt(pi)) Im[(1/z) p]
+}
+
+// One far-wing evaluation: Re[(1/sqrt(pi)) t/(1/2+t^2)], t = y - i x  (hum1_wei, :9834-9835) times the
+// line strength, as  (xx*Ay + Ay0) / ((xx + b1)*xx + b0)  with per-line constants from the fp64 prologue;
+// x = u*a + c with u = i - i0 an exact integer-valued float.  7 full-rate VALU ops + 1 v_rcp_f32.
+#define RTX_FARWING(u_, q_, num_, rden_)                      \
+  const float x_ = fmaf((u_), (q_).a, (q_).c);                \
+  const float xx_ = x_ * x_;                                  \
+  float num_ = fmaf(xx_, (q_).Ay, (q_).Ay0);                  \
+  float rden_ = __builtin_amdgcn_rcpf(fmaf(xx_ + (q_).b1, xx_, (q_).b0))
+
+// Function form of RTX_FARWING (the scatter kernel evaluates several rows in one scope).
+__device__ __forceinline__ void farwing(float u, const LineRec& q, float& x, float& num, float& rden) {
+  x = fmaf(u, q.a, q.c);
+  const float xx = x * x;
+  num = fmaf(xx, q.Ay, q.Ay0);
+  rden = __builtin_amdgcn_rcpf(fmaf(xx + q.b1, xx, q.b0));
+}

@@ -448,7 +448,12 @@ def test_full_c3_width_properties():
     OD1 = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
     OD2 = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], 2.0 * a["MFs_VAL"], a["MFs_ID"])
     ref_slice = OD[:, sh.offset:sh.offset + sh.n]
-    assert torch.equal(OD1, ref_slice), "wavenumber shard differs from the same slice of the full grid"
+    import os
+    if os.environ.get("RADTXFR_VOIGT_KERNEL") == "gather":  # the gather kernel is bit-identical across tilings
+        assert torch.equal(OD1, ref_slice), "wavenumber shard differs from the same slice of the full grid"
+    else:  # the scatter kernel regroups fp32 sums per tile: last-bit differences only
+        d = ((OD1 - ref_slice).abs() / ref_slice.abs().clamp_min(1e-3 * float(ref_slice.max()))).max()
+        assert float(d) <= 1e-6, float(d)
     assert float(((OD2 - 2.0 * OD1).abs() / (2.0 * OD1).clamp_min(1e-30)).max()) <= 1e-6
     # (4) oracle on a 3000-point window of the full grid
     i0, n = 1234567, 3000
