@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
   // in the line loop, and the far-wing constants enter the VALU instructions as scalar operands.
   {
     const int base = 0;
-    for (int slot = rng.x + wave; slot < rng.y; slot += 4) {
-      const LineRec q = rec[slot];  // s_load: the 8 resident waves per SIMD cover its latency (a software prefetch measured slower)
+    const LineRec* __restrict__ pq = rec + (rng.x + wave);
+    for (int slot = rng.x + wave; slot < rng.y; slot += 4, pq += 4) {
+      const LineRec q = *pq;  // s_load: the 8 resident waves per SIMD cover its latency (a software prefetch measured slower)
 #if RTX_SC_ONELOAD
       asm volatile("" ::"s"(q.a), "s"(q.Ay));  // keep both halves of the record in ONE scalar-load batch, ahead of the reject test
 #endif
