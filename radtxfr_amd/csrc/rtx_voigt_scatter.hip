@@ -26,14 +26,8 @@
 #ifndef RTX_SC_ABLATE
 #define RTX_SC_ABLATE 0  /* timing experiments: 1 = no band rows, 2 = no band rows and no edge rows */
 #endif
-#ifndef RTX_SC_ONELOAD
-#define RTX_SC_ONELOAD 0  /* 1: fetch the whole record before the reject test (measured slower) */
-#endif
 #ifndef RTX_SC_ASYM
 #define RTX_SC_ASYM 1
-#endif
-#ifndef RTX_SC_STAGE
-#define RTX_SC_STAGE 0  // 1: stage candidate records through LDS (first version); 0: scalar loads per wave
 #endif
 #ifndef RTX_SC_ROWS
 #define RTX_SC_ROWS 20  // rows of 64 points per tile: 1280 points, 5 KiB of LDS per wave copy (measured: 16 -> 5.63 ms, 20 -> 5.35, 24 -> 5.42, 32 -> 6.1)
@@ -58,15 +52,7 @@ template <bool CORE64>
 __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
-#if RTX_SC_STAGE
-  constexpr int CHUNK = 256;
-#endif
   __shared__ float s_acc[4][TILE];  // one private tile per wave
-#if RTX_SC_STAGE
-  __shared__ LineRec s_rec[CHUNK];
-  __shared__ int s_list[CHUNK];     // kept slots, table order
-  __shared__ int s_cnt[4];
-#endif
 
   const int b = blockIdx.x;
   const int tile = (b & 7) * a.tiles_per_xcd + (b >> 3);  // XCD-aware: one contiguous run of tiles per XCD
@@ -88,56 +74,21 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
   const float lanef = (float)lane;
   bool touched = false;
 
-#if RTX_SC_STAGE
-  for (int base = rng.x; base < rng.y; base += CHUNK) {
-    // ---- stage 256 candidate records, keep those whose window (CORE64: whose small-y band) meets the tile ----
-    const int l = base + (int)threadIdx.x;
-    const bool valid = l < rng.y;
-    const float4* src = reinterpret_cast<const float4*>(rec + (valid ? l : rng.y - 1));
-    const float4 r0 = src[0], r1 = src[1];
-    const int4 r2 = reinterpret_cast<const int4*>(src)[2];  // i0, lo, hi, zw
-    {
-      float4* dst = reinterpret_cast<float4*>(&s_rec[threadIdx.x]);
-      dst[0] = r0;
-      dst[1] = r1;
-      reinterpret_cast<int4*>(dst)[2] = r2;
-    }
-    bool keep = valid && (r2.z > ia) && (r2.y < ib);
-    if (CORE64) keep = keep && (r2.w > 0) && (r1.z < 1.0f) && (r2.x + r2.w >= ia) && (r2.x - r2.w < ib);
-    const unsigned long long m = __ballot(keep);
-    const int pos = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_cnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) off += (w < wave) ? s_cnt[w] : 0;
-    const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (keep) s_list[off + pos] = (int)threadIdx.x;
-    __syncthreads();
-
-    // ---- this wave's lines: every 4th kept line, in table order ------------------------------------
-    for (int j = wave; j < total; j += 4) {
-      const int slot = __builtin_amdgcn_readfirstlane(s_list[j]);
-      const LineRec q = s_rec[slot];
-      const int qi0 = __builtin_amdgcn_readfirstlane(q.i0), qlo = __builtin_amdgcn_readfirstlane(q.lo);
-      const int qhi = __builtin_amdgcn_readfirstlane(q.hi), qzw = __builtin_amdgcn_readfirstlane(q.zw);
-#else
-  // No staging at all: the candidate records are wave-uniform data, so each wave fetches the records of ITS lines
-  // (every 4th candidate, table order) with scalar loads straight into SGPRs -- no LDS for records, no barriers
-  // in the line loop, and the far-wing constants enter the VALU instructions as scalar operands.
+  // No staging: the candidate records are wave-uniform data, so each wave fetches the records of ITS lines (every
+  // 4th candidate of the tile's range, table order) with scalar loads straight into SGPRs -- no LDS for records, no
+  // barrier in the line loop, and the far-wing constants enter the VALU instructions as scalar operands.
+  // Tried and measured slower on C3: staging the records through LDS with a ballot-compacted list (6.1 ms),
+  // fetching the whole record before the reject test (6.1), a software prefetch of the next record (6.2), and
+  // doing the set-up for 64 lines at once in vector code with v_readlane broadcasts (5.3); this form: 5.0 ms.
   {
     const int base = 0;
     const LineRec* __restrict__ pq = rec + (rng.x + wave);
     for (int slot = rng.x + wave; slot < rng.y; slot += 4, pq += 4) {
       const LineRec q = *pq;  // s_load: the 8 resident waves per SIMD cover its latency (a software prefetch measured slower)
-#if RTX_SC_ONELOAD
-      asm volatile("" ::"s"(q.a), "s"(q.Ay));  // keep both halves of the record in ONE scalar-load batch, ahead of the reject test
-#endif
       const int qi0 = __builtin_amdgcn_readfirstlane(q.i0), qlo = __builtin_amdgcn_readfirstlane(q.lo);
       const int qhi = __builtin_amdgcn_readfirstlane(q.hi), qzw = __builtin_amdgcn_readfirstlane(q.zw);
       if (!(qhi > ia && qlo < ib)) continue;  // empty windows have lo = hi = 0
       if (CORE64 && !(qzw > 0 && q.y < 1.0f && qi0 + qzw >= ia && qi0 - qzw < ib)) continue;
-#endif
       // tile-local window [lo_t, hi_t) and its rows [r_lo, r_hi); a row cut by a window edge is "partial".
       // Plain integer arithmetic (min/max/shift): this set-up runs 2.7e7 times per C3 pass on the CU's one scalar ALU.
       const int dlo = qlo - ia, dhi = qhi - ia;
@@ -261,9 +212,6 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
         }
       }
     }
-#if RTX_SC_STAGE
-    __syncthreads();
-#endif
   }
   __syncthreads();  // every wave's tile is complete
 
