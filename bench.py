@@ -12,7 +12,7 @@ Inputs (line table, atmosphere) are resident in HBM before the timed region.
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
-  roofline     -- dominant kernel (voigt_sum_kernel) algorithmic bytes / measured launch time vs 8 TB/s
+  roofline     -- dominant kernel (voigt_scatter_kernel, the line-sum) algorithmic bytes / measured launch time vs 8 TB/s
   cpu_baseline -- the NumPy oracle (port of the reference's CPU path) on a bounded sample, rank 0, N=1
 """
 import argparse
@@ -168,9 +168,9 @@ def main():
     for _ in range(min(args.steps, 5)):
         step(record=True)
         torch.cuda.synchronize()
-        t_voigt.append(ev[0].elapsed_time(ev[1]))  # prologue + tile ranges + voigt_sum_kernel
+        t_voigt.append(ev[0].elapsed_time(ev[1]))  # prologue + tile ranges + line-sum kernel (+ its empty fp64 pass)
         t_tud.append(ev[1].elapsed_time(ev[2]))
-    # isolate voigt_sum_kernel: time the prologue alone and subtract
+    # isolate the line-sum kernel: time the prologue alone and subtract
     lib = _lib.load()
     t_prep = []
     import ctypes as C
@@ -189,7 +189,7 @@ def main():
 
     if rank == 0:
         pts = float(N_WAVENUMBERS) * N_LAYERS
-        # algorithmic bytes of one voigt_sum_kernel launch (SURVEY 8d stage A): 4 B OD write per point
+        # algorithmic bytes of one line-sum launch (SURVEY 8d stage A): 4 B OD write per point
         # + one 48 B fp32 line record per (line, layer)
         alg_bytes = 4.0 * n_loc * N_LAYERS + 48.0 * lines.n * N_LAYERS
         achieved = alg_bytes / (ms_voigt * 1e-3) / 1e9
@@ -220,7 +220,7 @@ def main():
                        "n_wavenumbers": N_WAVENUMBERS, "n_layers": N_LAYERS, "n_lines": N_LINES, "n_angles": 30,
                        "line_table": "synthetic HITRAN-format H2O+CO2, seed 20261005",
                        "parallelism": f"wavenumber-sharded x{world}" + (" + 1 RCCL all-gather" if world > 1 else "")},
-            "roofline": {"kernel": "voigt_sum_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "voigt_scatter_kernel<false>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (cand[-1] if traffic is not None else None),
                          "ms_per_launch": ms_voigt, "algorithmic_bytes_per_launch": alg_bytes,

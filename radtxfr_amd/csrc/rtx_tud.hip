@@ -165,78 +165,143 @@ struct TudArgs {
   double c2l2e_over_T[TUD_MAX_LAYERS]; // 100*c2*log2(e)/T_k
   float ang_c[TUD_MAX_ANGLES];         // -log2(e)/cos(theta)
   float ang_w[TUD_MAX_ANGLES];         // cos(theta)*sin(theta)
+  float ang_cmin, ang_cmax;            // min / max of |ang_c| over the evaluated streams
   float mu_c[TUD_MAX_MU];              // -log2(e)*mu
   float mu[TUD_MAX_MU];
   unsigned int mask[TUD_MAX_ALT][TUD_MAX_LAYERS / 32];
   int count[TUD_MAX_ALT];
 };
 
-template <int NL>
+// 1 - exp(-OD*sec) = 1 - 2^y (y = OD*c <= 0), accurate to ~1e-7 RELATIVE also when it is tiny.
+// A layer's emissivity (1 - t) is what weights its Planck radiance in L <- t L + (1 - t) B; forming it as 1 - fl(t)
+// from v_exp_f32 loses everything once t is within a few ulp of 1 (an optically thin layer: the LWIR window),
+// and the error of the accumulated radiance then reaches 1e-5..1e-4 of a thin path's radiance. So:
+//   |y| <  1/8 : 1 - 2^y = -y*ln2*(1 + z/2 + z^2/6 + z^3/24 + z^4/120), z = y ln2   (truncation 7e-9)
+//   |y| >= 1/8 : 1 - v_exp_f32(y)                                                    (relative error <= 7e-7)
+#define TUD_THIN_Y 0.125f
+__device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
+  const float q = fmaf(fmaf(fmaf(fmaf(1.3333558146e-3f, y, 9.6181291076e-3f), y, 5.5504108665e-2f), y, 2.4022650696e-1f), y,
+                       6.9314718056e-1f);  // ln2^5/120, ln2^4/24, ln2^3/6, ln2^2/2, ln2
+  return -y * q;
+}
+
+// Layer loop outside (run-time trip count: any n_layers, no per-n_layers register blow-up), the slant streams
+// inside as NA independent recurrences held in registers (full ILP, no dependence between streams). One
+// wave-uniform decision per (wave, layer) -- every lane thick / every lane thin / mixed -- picks the cheapest
+// exact form for all NA streams of that layer, so the scalar unit sees ~10 instructions per layer, not per stream.
+//   thick : t = 2^y,             L <- t (L - B) + B          (the fp32 form of :372, 4 VALU per stream)
+//   thin  : e = em_thin(y),      L <- L + e (B - L)
+//   mixed : e = per-lane select, L <- L + e (B - L)
+// OD is read once per block of streams, coalesced along the wavenumber axis.
+template <int NA>
 __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.g.n) return;
-  float od[NL], B[NL];
+  const long long i_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < a.g.n;
+  const long long i = live ? i_raw : a.g.n - 1;  // dead lanes shadow the last point: ballots stay wave-wide
   const int nL = a.n_layers;
-#pragma unroll
-  for (int k = 0; k < NL; ++k) od[k] = (k < nL) ? a.OD[(size_t)k * a.ld + i] : 0.f;
-  {
-    const double x = grid_x(a.g, a.g.offset + i);
-    const double x100 = x * 100.0;
-    const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) B[k] = (k < nL) ? planck_f32(c1x3, x, a.c2l2e_over_T[k]) : 0.f;
-  }
-  // ---- transmittance + upwelling, per sensor altitude and slant factor (:346-356) ----------
-  for (int ia = 0; ia < a.n_alt; ++ia) {
+  const double x = grid_x(a.g, a.g.offset + i);
+  const double x100 = x * 100.0;
+  const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
+  const float* __restrict__ od_col = a.OD + i;
+
+  // ---- every further (altitude, slant factor) pair: transmittance + upwelling bottom-up (:346-356) ----------
+  for (int p = 1; p < a.n_alt * a.n_mu; ++p) {
+    const int ia = p / a.n_mu, im = p - ia * a.n_mu;
     const int cnt = a.count[ia];
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < NL; ++k)
-      if ((a.mask[ia][k >> 5] >> (k & 31)) & 1u) s += od[k];
-    for (int im = 0; im < a.n_mu; ++im) {
-      const float c = a.mu_c[im];
-      float Lu = 0.f;
-#pragma unroll
-      for (int k = 0; k < NL; ++k) {
-        if (k < cnt) {
-          const float t = __builtin_amdgcn_exp2f(od[k] * c);
-          Lu = fmaf(t, Lu - B[k], B[k]);  // t*Lu + (1-t)*B
-        }
+    const float c = a.mu_c[im];
+    float s = 0.f, Lu = 0.f;
+    for (int k = 0; k < nL; ++k) {
+      const float od = od_col[(size_t)k * a.ld];
+      if ((a.mask[ia][k >> 5] >> (k & 31)) & 1u) s += od;
+      if (k < cnt) {
+        const float B = planck_f32(c1x3, x, a.c2l2e_over_T[k]);
+        const float y = od * c;
+        const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
+        Lu = fmaf(e, B - Lu, Lu);  // t*Lu + (1-t)*B
       }
-      const size_t o = (size_t)(ia * a.n_mu + im) * (size_t)a.ld_out + (size_t)i;
+    }
+    if (live) {
+      const size_t o = (size_t)p * (size_t)a.ld_out + (size_t)i;
       a.tau[o] = a.return_od ? s * a.mu[im] : __builtin_amdgcn_exp2f(s * c);
       a.Lu[o] = Lu;
     }
   }
-  // ---- downwelling: n_ang streams, two at a time for ILP (:368-372, 387-388) ---------------
+  // ---- downwelling, NA streams at a time, top of the atmosphere downwards (:368-372, 387-388); the first
+  //      (altitude, slant) pair rides along with the first block and shares its OD loads and Planck values:
+  //      L-up = sum_k (1-t_k) B_k T_k with T_k = 2^(c * sum_{k<j<cnt} OD_j) the transmittance from the top of
+  //      layer k to the sensor -- the closed form of the bottom-up recurrence, all terms positive.
   const int nd = a.n_down;
+  const int cnt0 = a.count[0];
+  const float c0 = a.mu_c[0];
+  float s0 = 0.f, S0 = 0.f, Lu0 = 0.f;
   float acc = 0.f;
-  for (int ii = 0; ii < a.n_ang; ii += 2) {
-    const float c0 = a.ang_c[ii], c1 = a.ang_c[ii + 1];
-    float L0 = 0.f, L1 = 0.f;
+  for (int a0 = 0; a0 < a.n_ang; a0 += NA) {
+    float L[NA], cth[NA];
 #pragma unroll
-    for (int k = NL - 1; k >= 0; --k) {
-      if (k < nd) {
-        const float t0 = __builtin_amdgcn_exp2f(od[k] * c0);
-        const float t1 = __builtin_amdgcn_exp2f(od[k] * c1);
-        L0 = fmaf(t0, L0 - B[k], B[k]);
-        L1 = fmaf(t1, L1 - B[k], B[k]);
+    for (int q = 0; q < NA; ++q) {
+      L[q] = 0.f;
+      cth[q] = a.ang_c[a0 + q];  // slots past n_ang_real hold the weight-0 nadir stream
+    }
+    const float c_min = a.ang_cmin, c_max = a.ang_cmax;  // |c| range over the streams (nadir .. most oblique)
+    for (int k = (a0 == 0 ? nL : nd) - 1; k >= 0; --k) {
+      const float od = od_col[(size_t)k * a.ld];
+      const float B = planck_f32(c1x3, x, a.c2l2e_over_T[k]);
+      if (a0 == 0) {
+        if ((a.mask[0][k >> 5] >> (k & 31)) & 1u) s0 += od;
+        if (k < cnt0) {
+          const float y = od * c0;
+          const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
+          Lu0 = fmaf(e * B, __builtin_amdgcn_exp2f(S0 * c0), Lu0);
+          S0 += od;
+        }
+        if (k >= nd) continue;
+      }
+      const bool thick = od * c_min >= TUD_THIN_Y;  // even the nadir stream has |y| >= 1/8
+      const bool thin = od * c_max < TUD_THIN_Y;    // even the most oblique stream has |y| < 1/8
+      if (__ballot(thick) == ~0ull) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          const float t = __builtin_amdgcn_exp2f(od * cth[q]);
+          L[q] = fmaf(t, L[q] - B, B);
+        }
+      } else if (__ballot(thin) == ~0ull) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          const float e = em_thin(od * cth[q]);
+          L[q] = fmaf(e, B - L[q], L[q]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+          const float y = od * cth[q];
+          const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
+          L[q] = fmaf(e, B - L[q], L[q]);
+        }
       }
     }
-    acc = fmaf(L0, a.ang_w[ii], acc);
-    acc = fmaf(L1, a.ang_w[ii + 1], acc);
-    if (a.Ld_ang) {
-      a.Ld_ang[(size_t)ii * a.ld_out + i] = L0;
-      if (ii + 1 < a.n_ang_real) a.Ld_ang[(size_t)(ii + 1) * a.ld_out + i] = L1;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      acc = fmaf(L[q], a.ang_w[a0 + q], acc);
+      if (a.Ld_ang && live && a0 + q < a.n_ang_real) a.Ld_ang[(size_t)(a0 + q) * a.ld_out + i] = L[q];
     }
   }
-  a.Ld[i] = acc * a.inv_wsum;
+  if (live) {
+    a.tau[i] = a.return_od ? s0 * a.mu[0] : __builtin_amdgcn_exp2f(s0 * c0);
+    a.Lu[i] = Lu0;
+    a.Ld[i] = acc * a.inv_wsum;
+  }
 }
 
-template <int NL>
-static int launch_tud(const TudArgs& a, hipStream_t st) {
+template <int NA>
+static int launch_tud(TudArgs& a, int na, hipStream_t st) {
+  const int na_pad = na == 0 ? NA : ((na + NA - 1) / NA) * NA;  // at least one block: it carries tau and L-up
+  float cmin = (float)LOG2E, cmax = (float)LOG2E;  // the pads are nadir streams and count for the thick/thin test
+  for (int q = 0; q < na; ++q) { cmin = fminf(cmin, -a.ang_c[q]); cmax = fmaxf(cmax, -a.ang_c[q]); }
+  for (int q = na; q < na_pad; ++q) { a.ang_c[q] = (float)(-LOG2E); a.ang_w[q] = 0.f; }
+  a.ang_cmin = cmin; a.ang_cmax = cmax;
+  a.n_ang = na_pad;
   const long long blocks = (a.g.n + 255) / 256;
-  hipLaunchKernelGGL(tud_kernel<NL>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(tud_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }
@@ -249,7 +314,7 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
   if (n_layers < 1 || n_layers > TUD_MAX_LAYERS) RTX_FAIL("n_layers=%d outside [1,%d]", n_layers, TUD_MAX_LAYERS);
   if (n_alt < 1 || n_alt > TUD_MAX_ALT) RTX_FAIL("n_alt=%d outside [1,%d]", n_alt, TUD_MAX_ALT);
   if (n_mu < 1 || n_mu > TUD_MAX_MU) RTX_FAIL("n_mu=%d outside [1,%d]", n_mu, TUD_MAX_MU);
-  if (n_angle < 1 || n_angle > TUD_MAX_ANGLES - 1) RTX_FAIL("n_angle=%d outside [1,%d]", n_angle, TUD_MAX_ANGLES - 1);
+  if (n_angle < 1 || n_angle > TUD_MAX_ANGLES - 32) RTX_FAIL("n_angle=%d outside [1,%d]", n_angle, TUD_MAX_ANGLES - 32);
   if (n_down < 0 || n_down > n_layers) RTX_FAIL("n_down=%d outside [0,%d]", n_down, n_layers);
   if (ld < grid->n || ld_out < grid->n) RTX_FAIL("leading dimension smaller than the shard");
   if (grid->n == 0) return 0;
@@ -284,15 +349,15 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
     ++na;
   }
   a.n_ang_real = na;
-  if (na & 1) { a.ang_c[na] = (float)(-LOG2E); a.ang_w[na] = 0.f; ++na; }
-  a.n_ang = na;
   a.inv_wsum = (float)(1.0 / wsum);  // n_angle==1: 1/0 = inf, acc=0 -> NaN like the reference's 0/0
   if (na == 0) a.inv_wsum = NAN;
+  // streams per register block: the smallest instantiated width that holds them all (N_angle = 30 -> 29
+  // evaluated -> 29 registers, no padding); more than 32 streams run in blocks of 32
   hipStream_t st = (hipStream_t)stream;
-  if (n_layers <= 16) return launch_tud<16>(a, st);
-  if (n_layers <= 32) return launch_tud<32>(a, st);
-  if (n_layers <= 48) return launch_tud<48>(a, st);
-  if (n_layers <= 64) return launch_tud<64>(a, st);
-  if (n_layers <= 96) return launch_tud<96>(a, st);
-  return launch_tud<128>(a, st);
+  if (na <= 4) return launch_tud<4>(a, na, st);
+  if (na <= 8) return launch_tud<8>(a, na, st);
+  if (na <= 16) return launch_tud<16>(a, na, st);
+  if (na <= 24) return launch_tud<24>(a, na, st);
+  if (na <= 29) return launch_tud<29>(a, na, st);
+  return launch_tud<32>(a, na, st);
 }
