@@ -243,8 +243,15 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
       cth[q] = a.ang_c[a0 + q];  // slots past n_ang_real hold the weight-0 nadir stream
     }
     const float c_min = a.ang_cmin, c_max = a.ang_cmax;  // |c| range over the streams (nadir .. most oblique)
-    for (int k = (a0 == 0 ? nL : nd) - 1; k >= 0; --k) {
-      const float od = od_col[(size_t)k * a.ld];
+    // the OD loads run two layers ahead of their use: with ~4 waves per SIMD a load issued where it is
+    // needed leaves its whole latency exposed once per layer
+    const int k_top = (a0 == 0 ? nL : nd) - 1;
+    float od_1 = k_top >= 0 ? od_col[(size_t)k_top * a.ld] : 0.f;
+    float od_2 = k_top >= 1 ? od_col[(size_t)(k_top - 1) * a.ld] : 0.f;
+    for (int k = k_top; k >= 0; --k) {
+      const float od = od_1;
+      od_1 = od_2;
+      od_2 = od_col[(size_t)(k >= 2 ? k - 2 : 0) * a.ld];
       const float B = planck_f32(c1x3, x, a.c2l2e_over_T[k]);
       if (a0 == 0) {
         if ((a.mask[0][k >> 5] >> (k & 31)) & 1u) s0 += od;
