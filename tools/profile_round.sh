@@ -1,0 +1,20 @@
+#!/bin/bash
+# One gpurun call that produces everything profiles/ holds for a round:
+#   gpurun -- 'bash tools/profile_round.sh r1'
+# then, back in the container:  python tools/profile_summarize.py r1
+# Counters are collected in their own passes (one --pmc set per run, never together with a trace).
+set -o pipefail
+TAG=${1:-r1}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ARGS="--steps 10 --warmup 3"
+timeout -k 10 300 python3 bench.py $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline > "$OUT/bench_prof.json" 2> "$OUT/trace.err" || exit 2
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES" "busy:SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
+  name=${pass%%:*}; ctrs=${pass#*:}
+  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$name" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$name.err" || exit 3
+done
+echo done

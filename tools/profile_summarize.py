@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into the files profiles/ keeps:
+  <tag>_bench_n1.json            the bench line of the un-profiled run
+  <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of the same command
+  <tag>_pmc_counters.txt         per-kernel, per-launch averages of every --pmc pass
+  <tag>_pmc_hbm_traffic.json     HBM bytes per launch of the dominant kernel (FETCH_SIZE doubled on gfx950, per
+                                 /opt/skills/guides/MI355X_MICROARCH.md; both counters count KiB)
+usage: python tools/profile_summarize.py r1 [dominant-kernel-substring]"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+dom = sys.argv[2] if len(sys.argv) > 2 else "voigt_scatter_kernel<false>"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench_n1.json"))
+stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
+assert stats, "no kernel_stats.csv"
+shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+
+per = {}
+lines = []
+for pdir in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(pdir):
+        continue
+    for f in glob.glob(os.path.join(pdir, "**", "*_counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        calls = collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[(k, r["Counter_Name"])] += 1
+        lines.append(f"# pass {os.path.basename(pdir)}  (rocprofv3 --pmc, its own run; values are averages per launch)")
+        for k, v in sorted(agg.items()):
+            if k.startswith("__amd") or "at::native" in k:
+                continue
+            n = max(calls[(k, c)] for c in v)
+            row = {c: val / n for c, val in sorted(v.items())}
+            per.setdefault(k, {}).update(row)
+            lines.append(f"{k[:64]:64s} launches={n:3d} " + " ".join(f"{c}={val:.6g}" for c, val in row.items()))
+with open(os.path.join(dst, f"{tag}_pmc_counters.txt"), "w") as fh:
+    fh.write("\n".join(lines) + "\n")
+
+hit = [k for k in per if dom in k]
+if hit and "FETCH_SIZE" in per[hit[0]] and "WRITE_SIZE" in per[hit[0]]:
+    c = per[hit[0]]
+    out = {"source": f"profiles/{tag}_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes)",
+           "workload": "C3 n_gpus=1", "kernel": hit[0],
+           "fetch_size_kb_per_launch": c["FETCH_SIZE"], "write_size_kb_per_launch": c["WRITE_SIZE"],
+           "fetch_correction": 2.0,
+           "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0}
+    with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read()[:1500])
+print(open(os.path.join(dst, f"{tag}_pmc_counters.txt")).read())
