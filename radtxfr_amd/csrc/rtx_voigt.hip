@@ -287,7 +287,8 @@ extern "C" int rtx_voigt_tile_points(void) {
 
 // rtx_voigt_scatter.hip
 int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64, int64_t ld,
-                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t));
+                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t),
+                          int nodal);
 
 static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_layers, int n_tiles, int tile, hipStream_t st) {
   RangeArgs ra;
@@ -296,16 +297,18 @@ static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_la
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles + 255) / 256, n_layers), dim3(256), 0, st, ra);
 }
 
-// RADTXFR_VOIGT_KERNEL=gather selects the register-accumulator kernel of this file (bit-identical across
-// wavenumber shards); the default is the scatter kernel (rtx_voigt_scatter.hip), which is faster.
-static bool use_gather_kernel() {
+// RADTXFR_VOIGT_KERNEL selects the line-sum formulation: "nodal" (default; rtx_voigt_scatter.hip, far rows at
+// Chebyshev nodes), "scatter" (same file, every row point by point) or "gather" (the register-accumulator kernel
+// of this file, bit-identical across wavenumber shards). The alternatives stay for A/B timing and cross-checks.
+static int voigt_kernel_choice() {  // 0 nodal, 1 scatter, 2 gather
   static int cached = -1;
   if (cached < 0) {
     const char* e = getenv("RADTXFR_VOIGT_KERNEL");
-    cached = (e && strcmp(e, "gather") == 0) ? 1 : 0;
+    cached = (e && strcmp(e, "gather") == 0) ? 2 : (e && strcmp(e, "scatter") == 0) ? 1 : 0;
   }
-  return cached == 1;
+  return cached;
 }
+static bool use_gather_kernel() { return voigt_kernel_choice() == 2; }
 
 extern "C" int rtx_voigt_sum(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64,
                              int64_t ld, void* stream) {
@@ -325,7 +328,7 @@ extern "C" int rtx_voigt_sum(const rtx_prep* P, const rtx_grid* grid, int n_laye
     if (out_f64) RTX_HIP(hipMemset2DAsync(out_f64, ld * sizeof(double), 0, grid->n * sizeof(double), n_layers, st));
     return 0;
   }
-  if (!use_gather_kernel()) return rtx_voigt_sum_scatter(P, grid, n_layers, out_f32, out_f64, ld, st, launch_tile_ranges);
+  if (!use_gather_kernel()) return rtx_voigt_sum_scatter(P, grid, n_layers, out_f32, out_f64, ld, st, launch_tile_ranges, voigt_kernel_choice() == 0);
   launch_tile_ranges(P, grid, n_layers, n_tiles, TILE, st);
   RTX_LAUNCH_CHECK();
   VsArgs a;

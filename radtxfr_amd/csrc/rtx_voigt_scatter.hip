@@ -1,30 +1,40 @@
 // Voigt line-sum, "scatter into per-wave LDS tiles" formulation (the default; rtx_voigt.hip holds the
 // register-accumulator gather kernel it replaced and shares the record layout and the Weideman code).
 //
-// Why a second formulation: in the gather kernel a (line, wave) visit costs ~60 cycles of bookkeeping
-// (record re-read from LDS, scalar set-up) before any useful work, every line is visited by every wave it
-// reaches (6e7 visits on the C3 workload, ~1.8 ms), and window edges / Weideman bands force whole visits
-// through slow code because register accumulators need compile-time row indices.
-// Here a workgroup owns a tile of SC_TILE consecutive grid points of one layer; EACH LINE IS TAKEN BY
-// EXACTLY ONE WAVE, which sweeps the line's window across the whole tile row by row (64 points per
-// wave-instruction) and accumulates into ITS OWN copy of the tile in LDS (plain ds_read/add/ds_write: no
-// other wave touches that copy, so no atomics and a fixed summation order). Rows are a run-time loop, so
-//   - the per-line set-up is paid once per (line, tile) instead of once per (line, wave),
-//   - only the first/last row of a window is masked and only the 2-3 band rows run the Weideman code,
-//   - interior rows run a 4-row software-pipelined body: 7 VALU + v_rcp_f32 + one LDS read and write per row.
-// At the end the 4 copies are added in a fixed order and stored with coalesced 256-B wave stores.
-// LDS accumulate rate (tools/ubench_lds.hip): 4.7 cycles per wave-level read+add+write per CU, i.e. ~80 % of
-// what four SIMDs demand at 22 VALU cycles per row -- the vector pipes stay the binding resource.
+// A workgroup owns a tile of SC_TILE consecutive grid points of one layer; EACH LINE IS TAKEN BY EXACTLY ONE
+// WAVE, which accumulates the line into ITS OWN copy of the tile in LDS (plain ds_read/add/ds_write: no other
+// wave touches that copy, so no atomics and a fixed summation order). Rows (64 points = one wave-instruction)
+// are a run-time loop, so only the first/last row of a window is masked and only the 2-3 band rows run the
+// Weideman code. At the end the 4 copies are added in a fixed order and stored with coalesced 256-B stores.
 //
-// Summation order: lines are dealt round-robin to the 4 waves in table order, so a point's value is a fixed
-// function of the tiling; a different tiling (another wavenumber shard) regroups the fp32 sums and may differ
-// in the last bits (the gather kernel is bit-identical across shards; tests allow 1e-6 here).
+// Two kernels:
+//  voigt_scatter_kernel<CORE64>  every row a window reaches is evaluated point by point (7 VALU + v_rcp_f32 + one
+//                                LDS read/write per row and line). CORE64 = true is the fp64 pass for y < 1 lines.
+//  voigt_nodal_kernel            (default main pass) the same, but only for the rows NEAR a line: within
+//                                SC_NEAR rows of its centre, in its Weideman band, or cut by a window edge.
+//                                On every other row the line is a smooth far wing -- the rational far-wing form of
+//                                hum1_wei, poles at |nu - nu0| ~ gamma0 -- and is evaluated at the row's 8
+//                                Chebyshev nodes only; the nodal sums of all far lines are carried to the 64
+//                                grid points once per tile by the 64x8 Lagrange matrix (interpolation is linear,
+//                                so interpolating the sum equals summing the interpolants). With the nearest
+//                                pole >= 3 rows from the row the degree-7 interpolant is within 1.4e-8 of each
+//                                line's own (positive) contribution (tools/gen_cheb.py), far
+//                                below the fp32 rounding of the direct evaluation. The far evaluation runs with
+//                                lane = (line, node): 8 lines x 8 nodes per wave-instruction, records fetched
+//                                by vector loads, no scalar work per line: ~1.6 VALU slots per (line, row)
+//                                against ~11 for the point-by-point form, and C3's windows are ~80 rows wide.
+//
+// Summation order: a point's value is a fixed function of the tiling; a different tiling (another wavenumber
+// shard) regroups the fp32 sums and may differ in the last bits (the gather kernel is bit-identical across
+// shards; tests allow 1e-6 here).
 #include "rtx_common.h"
 
 #include "rtx_voigt_math.h"
 
+#include "cheb8_64.inc"
+
 #ifndef RTX_SC_ABLATE
-#define RTX_SC_ABLATE 0  /* timing experiments: 1 = no band rows, 2 = no band rows and no edge rows */
+#define RTX_SC_ABLATE 0  /* timing experiments: 1 = no band rows, 2 = no band rows and no edge rows, 3 = no far rows */
 #endif
 #ifndef RTX_SC_ASYM
 #define RTX_SC_ASYM 1
@@ -32,6 +42,10 @@
 #ifndef RTX_SC_ROWS
 #define RTX_SC_ROWS 20  // rows of 64 points per tile: 1280 points, 5 KiB of LDS per wave copy (measured: 16 -> 5.63 ms, 20 -> 5.35, 24 -> 5.42, 32 -> 6.1)
 #endif
+#ifndef RTX_SC_NEAR
+#define RTX_SC_NEAR 3  // rows either side of the centre row that stay point-by-point in the nodal kernel
+#endif
+static_assert(RTX_SC_ROWS <= 31, "row masks are 32-bit");
 
 struct ScArgs {
   const LineRec* rec;
@@ -47,6 +61,202 @@ struct ScArgs {
   long long ld;
   double inv_scale;
 };
+
+// Row geometry of one line in one tile, in plain integer arithmetic so that the scalar per-line code and the
+// per-lane far-row masks agree exactly. Rows are tile-local, 64 points each.
+struct RowGeom {
+  int r_lo, r_hi;  // rows the window [lo, hi) reaches: [r_lo, r_hi)
+  int c0, c1;      // rows wholly inside the window: [c0, c1)
+  int z0, z1;      // rows touching the Weideman band: [z0, z1] (z0 > z1: none in this tile)
+  int n0, n1;      // near zone [n0, n1] (unclamped): centre row +- SC_NEAR, widened to the band rows
+  bool part_l, part_r;
+};
+__device__ __forceinline__ RowGeom row_geom(int qi0, int qlo, int qhi, int qzw, int ia, int nt) {
+  constexpr int ROWS = RTX_SC_ROWS;
+  RowGeom g;
+  const int dlo = qlo - ia, dhi = qhi - ia;
+  const int lo_t = dlo > 0 ? dlo : 0, hi_t = dhi < nt ? dhi : nt;
+  g.r_lo = lo_t >> 6;
+  g.r_hi = (hi_t + 63) >> 6;
+  g.c0 = (lo_t + 63) >> 6;
+  g.c1 = dhi < nt ? hi_t >> 6 : g.r_hi;  // a ragged last row of the GRID is not an edge: its stores are masked
+  g.part_l = g.c0 != g.r_lo;
+  g.part_r = g.c1 != g.r_hi;
+  const int zw = qzw > 0 ? qzw : 0;
+  const int zl = qi0 - zw - ia, zh = qi0 + zw - ia;  // |qi0| <= 1e8 + n (prologue clamp), zw <= 4e7: no overflow
+  g.z0 = ROWS;
+  g.z1 = -1;
+  if (qzw > 0 && zh >= 0 && zl < 64 * ROWS) {
+    g.z0 = zl > 0 ? zl >> 6 : 0;
+    g.z1 = (zh >> 6) < ROWS - 1 ? zh >> 6 : ROWS - 1;
+  }
+  const int rc = (qi0 - ia) >> 6;  // arithmetic shift: floor
+  const int bl = zl >> 6, bh = zh >> 6;
+  g.n0 = (rc - RTX_SC_NEAR) < bl ? rc - RTX_SC_NEAR : bl;
+  g.n1 = (rc + RTX_SC_NEAR) > bh ? rc + RTX_SC_NEAR : bh;
+  return g;
+}
+
+// One line, taken by one wave: point-by-point rows into the wave's LDS tile. NODAL: only the rows of the near
+// zone (the far rows were added at the Chebyshev nodes); the record arrives through scalar loads.
+template <bool CORE64, bool NODAL>
+__device__ __forceinline__ void visit_line(const ScArgs& a, const LineRec* __restrict__ rec, const LineRec64* __restrict__ rec64,
+                                           int slot, float* __restrict__ acc, int ia, int ib, int nt, int lane, float lanef,
+                                           bool& touched) {
+  const LineRec q = rec[slot];  // s_load: the resident waves cover its latency (a software prefetch measured slower)
+  const int qi0 = __builtin_amdgcn_readfirstlane(q.i0), qlo = __builtin_amdgcn_readfirstlane(q.lo);
+  const int qhi = __builtin_amdgcn_readfirstlane(q.hi), qzw = __builtin_amdgcn_readfirstlane(q.zw);
+  if (!(qhi > ia && qlo < ib)) return;  // empty windows have lo = hi = 0
+  if (CORE64 && !(qzw > 0 && q.y < 1.0f && qi0 + qzw >= ia && qi0 - qzw < ib)) return;
+  // Plain integer arithmetic (min/max/shift): this set-up runs on the CU's one scalar ALU.
+  const RowGeom g = row_geom(qi0, qlo, qhi, qzw, ia, nt);
+  const int r_lo = g.r_lo, r_hi = g.r_hi, z0 = g.z0, z1 = g.z1;
+  // point-by-point interior rows: [c0, c1), clipped to the near zone for the nodal kernel
+  const int c0 = NODAL ? (g.c0 > g.n0 ? g.c0 : g.n0) : g.c0;
+  const int c1 = NODAL ? (g.c1 < g.n1 + 1 ? g.c1 : g.n1 + 1) : g.c1;
+  // u = i - i0 as a float: integer-valued, exact while |i - i0| < 2^24; |i0| is clamped by the prologue
+  const float u0 = (float)(ia - qi0) + lanef;
+  const float ulo = (float)(qlo - qi0), uhi = (float)(qhi - qi0);
+  const float zw_f = qzw > 0 ? (float)qzw : -1.0f;
+
+  if (!CORE64) {
+    // interior rows = [c0, c1) minus [z0, z1]: run 0 = [c0, min(c1, z0)), run 1 = [max(c0, z1 + 1), c1)
+    for (int run = 0; run < 2; ++run) {
+      if (run == 1 && z0 > z1) break;  // no band: run 0 already covered [c0, c1)
+      int r = run == 0 ? c0 : (z1 + 1 > c0 ? z1 + 1 : c0);
+      const int re = run == 0 ? (z0 < c1 ? z0 : c1) : c1;
+      if (!NODAL) {
+        for (; r + 8 <= re; r += 8) {  // 8 rows in flight: halves the scalar loop overhead (the CU's one scalar ALU is busy)
+          float* p = acc + r * 64 + lane;
+          float av[8], nv[8], dv[8], xv;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) av[t] = p[64 * t];
+          const float ub = u0 + (float)(64 * r);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) farwing(ub + (float)(64 * t), q, xv, nv[t], dv[t]);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) p[64 * t] = fmaf(nv[t], dv[t], av[t]);
+        }
+      }
+      for (; r + 4 <= re; r += 4) {  // 4 rows in flight: LDS reads, 4 evaluations, LDS writes
+        float* p = acc + r * 64 + lane;
+        const float a0 = p[0], a1 = p[64], a2 = p[128], a3 = p[192];
+        const float ub = u0 + (float)(64 * r);
+        float x0, n0, d0, x1, n1, d1, x2, n2, d2, x3, n3, d3;
+        farwing(ub, q, x0, n0, d0);
+        farwing(ub + 64.0f, q, x1, n1, d1);
+        farwing(ub + 128.0f, q, x2, n2, d2);
+        farwing(ub + 192.0f, q, x3, n3, d3);
+        p[0] = fmaf(n0, d0, a0);
+        p[64] = fmaf(n1, d1, a1);
+        p[128] = fmaf(n2, d2, a2);
+        p[192] = fmaf(n3, d3, a3);
+      }
+      for (; r < re; ++r) {
+        float* p = acc + r * 64 + lane;
+        float x0, n0, d0;
+        farwing(u0 + (float)(64 * r), q, x0, n0, d0);
+        p[0] = fmaf(n0, d0, p[0]);
+      }
+    }
+    // partial rows (at most two) outside the band rows: far-wing formula, lanes outside [lo,hi) masked
+    const int eL = g.part_l ? r_lo : -1;
+    const int eR = (g.part_r && r_hi - 1 != eL) ? r_hi - 1 : -1;
+    for (int pass = 0; pass < (RTX_SC_ABLATE == 2 ? 0 : 2); ++pass) {
+      const int r = pass == 0 ? eL : eR;
+      if (r < 0 || (r >= z0 && r <= z1)) continue;
+      float* p = acc + r * 64 + lane;
+      const float u = u0 + (float)(64 * r);
+      float x0, n0, d0;
+      farwing(u, q, x0, n0, d0);
+      n0 = (u >= ulo && u < uhi) ? n0 : 0.f;
+      p[0] = fmaf(n0, d0, p[0]);
+    }
+  }
+  // band rows: region test + Weideman for lanes inside |x|+y<15, far-wing formula elsewhere, window-masked.
+  // A line with y < 1 belongs to the CORE64 pass (same predicate on the same fp32 record in both passes).
+  const bool small_y = q.y < 1.0f;
+  if (z0 <= z1 && (RTX_SC_ABLATE == 0 || RTX_SC_ABLATE == 3)) {
+    const int zb = z0 > r_lo ? z0 : r_lo, ze = z1 < r_hi - 1 ? z1 : r_hi - 1;
+    for (int r = zb; r <= ze; ++r) {
+      float* p = acc + r * 64 + lane;
+      const int i = ia + 64 * r + lane;
+      const float u = u0 + (float)(64 * r);
+      float x, num, rden;
+      farwing(u, q, x, num, rden);
+      const bool in_band = fabsf(u) <= zw_f;
+      if (CORE64 ? small_y : !small_y) {
+        // hum1_wei's switch |x|+y < 15 (:9840): fp32 decides unless a lane sits within 2e-3 of it; those
+        // lanes repeat the test exactly as the reference forms it, in fp64: x = -Im Z1 = -((sg0 - sg)*cte)
+        const float s32 = fabsf(x) + q.y;
+        bool wz = s32 < 15.0f;
+        const bool near = fabsf(s32 - 15.0f) < 2e-3f;
+        if (CORE64 || __ballot(near)) {
+          const LineRec64 Q = rec64[slot];
+          const double sg = grid_x(a.g, a.g.offset + (long long)i);
+          const double x64 = -((Q.sg0 - sg) * Q.cte);
+          const bool wz64 = fabs(x64) + Q.y < 15.0;
+          wz = (CORE64 || near) ? wz64 : wz;
+          if (CORE64 && wz) {
+            num = (float)(Q.A * weideman_re<double>(x64, Q.y));
+            rden = 1.0f;
+          }
+        }
+        if (!CORE64 && wz) {
+          // pressure-broadened lines (y >= 6: ~70 % of the band lines of C3): the whole band has |z| >= 6 and the
+          // 6-term asymptotic series agrees with Weideman-24 to 6.4e-8; Weideman itself only for y < 6
+          if (RTX_SC_ASYM && q.y >= 6.0f) num = q.A * asym6_re(x, q.y);
+          else num = q.A * weideman_re<float>(x, q.y);
+          rden = 1.0f;
+        }
+        if (CORE64) {  // this pass adds ONLY the band lanes of small-y lines
+          num = in_band ? num : 0.f;
+          touched = true;
+        }
+      } else {
+        // the other pass owns this line's band lanes; here only the far-wing lanes of the row count
+        num = (CORE64 || in_band) ? 0.f : num;
+      }
+      num = (u >= ulo && u < uhi) ? num : 0.f;
+      p[0] = fmaf(num, rden, p[0]);
+    }
+  }
+}
+
+// Fixed-order sum of the four private tiles (+ the interpolated nodal sums), coalesced stores.
+template <bool CORE64, bool NODAL>
+__device__ __forceinline__ void store_tile(const ScArgs& a, const float (*s_acc)[64 * RTX_SC_ROWS],
+                                           const float (*s_nodal)[RTX_SC_ROWS][CHEB_N], int k, int ia, int ib, int wave, int lane) {
+  constexpr int ROWS = RTX_SC_ROWS;
+  float wl[CHEB_N];
+  if (NODAL) {
+#pragma unroll
+    for (int j = 0; j < CHEB_N; ++j) wl[j] = CHEB_W[lane][j];
+  }
+#pragma unroll 4
+  for (int r = wave; r < ROWS; r += 4) {
+    const int t = r * 64 + lane;
+    const long long i = (long long)ia + t;
+    float v = (s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t]);
+    if (NODAL) {
+      float f = 0.f;
+#pragma unroll
+      for (int j = 0; j < CHEB_N; ++j)
+        f = fmaf(wl[j], (s_nodal[0][r][j] + s_nodal[1][r][j]) + (s_nodal[2][r][j] + s_nodal[3][r][j]), f);
+      v += f;
+    }
+    if (i < (long long)ib) {
+      const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
+      if (CORE64) {
+        if (a.out32) a.out32[o] += v;
+        if (a.out64) a.out64[o] += (double)v * a.inv_scale;
+      } else {
+        if (a.out32) a.out32[o] = v;
+        if (a.out64) a.out64[o] = (double)v * a.inv_scale;
+      }
+    }
+  }
+}
 
 template <bool CORE64>
 __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
@@ -80,139 +290,7 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
   // Tried and measured slower on C3: staging the records through LDS with a ballot-compacted list (6.1 ms),
   // fetching the whole record before the reject test (6.1), a software prefetch of the next record (6.2), and
   // doing the set-up for 64 lines at once in vector code with v_readlane broadcasts (5.3); this form: 5.0 ms.
-  {
-    const int base = 0;
-    const LineRec* __restrict__ pq = rec + (rng.x + wave);
-    for (int slot = rng.x + wave; slot < rng.y; slot += 4, pq += 4) {
-      const LineRec q = *pq;  // s_load: the 8 resident waves per SIMD cover its latency (a software prefetch measured slower)
-      const int qi0 = __builtin_amdgcn_readfirstlane(q.i0), qlo = __builtin_amdgcn_readfirstlane(q.lo);
-      const int qhi = __builtin_amdgcn_readfirstlane(q.hi), qzw = __builtin_amdgcn_readfirstlane(q.zw);
-      if (!(qhi > ia && qlo < ib)) continue;  // empty windows have lo = hi = 0
-      if (CORE64 && !(qzw > 0 && q.y < 1.0f && qi0 + qzw >= ia && qi0 - qzw < ib)) continue;
-      // tile-local window [lo_t, hi_t) and its rows [r_lo, r_hi); a row cut by a window edge is "partial".
-      // Plain integer arithmetic (min/max/shift): this set-up runs 2.7e7 times per C3 pass on the CU's one scalar ALU.
-      const int dlo = qlo - ia, dhi = qhi - ia;
-      const int lo_t = dlo > 0 ? dlo : 0, hi_t = dhi < nt ? dhi : nt;
-      const int r_lo = lo_t >> 6, r_hi = (hi_t + 63) >> 6;
-      const int c0 = (lo_t + 63) >> 6;               // rows wholly inside the window: [c0, c1)
-      const int c1 = dhi < nt ? hi_t >> 6 : r_hi;    // a ragged last row of the GRID is not an edge: its stores are masked
-      const bool part_l = c0 != r_lo, part_r = c1 != r_hi;
-      // rows touching the Weideman band: [z0, z1] (z0 > z1: none in this tile)
-      int z0 = ROWS, z1 = -1;
-      if (qzw > 0) {
-        const int zl = qi0 - qzw - ia, zh = qi0 + qzw - ia;
-        if (zh >= 0 && zl < TILE) {
-          z0 = zl > 0 ? zl >> 6 : 0;
-          z1 = (zh >> 6) < ROWS - 1 ? zh >> 6 : ROWS - 1;
-        }
-      }
-      // u = i - i0 as a float: integer-valued, exact while |i - i0| < 2^24; |i0| is clamped by the prologue
-      const float u0 = (float)(ia - qi0) + lanef;
-      const float ulo = (float)(qlo - qi0), uhi = (float)(qhi - qi0);
-      const float zw_f = qzw > 0 ? (float)qzw : -1.0f;
-
-      if (!CORE64) {
-        // interior rows = [c0, c1) minus [z0, z1]: run 0 = [c0, min(c1, z0)), run 1 = [max(c0, z1 + 1), c1)
-        for (int run = 0; run < 2; ++run) {
-          if (run == 1 && z0 > z1) break;  // no band: run 0 already covered [c0, c1)
-          int r = run == 0 ? c0 : (z1 + 1 > c0 ? z1 + 1 : c0);
-          const int re = run == 0 ? (z0 < c1 ? z0 : c1) : c1;
-          for (; r + 8 <= re; r += 8) {  // 8 rows in flight: halves the scalar loop overhead (the CU's one scalar ALU is busy)
-            float* p = acc + r * 64 + lane;
-            float av[8], nv[8], dv[8], xv;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) av[t] = p[64 * t];
-            const float ub = u0 + (float)(64 * r);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) farwing(ub + (float)(64 * t), q, xv, nv[t], dv[t]);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) p[64 * t] = fmaf(nv[t], dv[t], av[t]);
-          }
-          for (; r + 4 <= re; r += 4) {  // 4 rows in flight: LDS reads, 4 evaluations, LDS writes
-            float* p = acc + r * 64 + lane;
-            const float a0 = p[0], a1 = p[64], a2 = p[128], a3 = p[192];
-            const float ub = u0 + (float)(64 * r);
-            float x0, n0, d0, x1, n1, d1, x2, n2, d2, x3, n3, d3;
-            farwing(ub, q, x0, n0, d0);
-            farwing(ub + 64.0f, q, x1, n1, d1);
-            farwing(ub + 128.0f, q, x2, n2, d2);
-            farwing(ub + 192.0f, q, x3, n3, d3);
-            p[0] = fmaf(n0, d0, a0);
-            p[64] = fmaf(n1, d1, a1);
-            p[128] = fmaf(n2, d2, a2);
-            p[192] = fmaf(n3, d3, a3);
-          }
-          for (; r < re; ++r) {
-            float* p = acc + r * 64 + lane;
-            float x0, n0, d0;
-            farwing(u0 + (float)(64 * r), q, x0, n0, d0);
-            p[0] = fmaf(n0, d0, p[0]);
-          }
-        }
-        // partial rows (at most two) outside the band rows: far-wing formula, lanes outside [lo,hi) masked
-        const int eL = part_l ? r_lo : -1;
-        const int eR = (part_r && r_hi - 1 != eL) ? r_hi - 1 : -1;
-        for (int pass = 0; pass < (RTX_SC_ABLATE == 2 ? 0 : 2); ++pass) {
-          const int r = pass == 0 ? eL : eR;
-          if (r < 0 || (r >= z0 && r <= z1)) continue;
-          float* p = acc + r * 64 + lane;
-          const float u = u0 + (float)(64 * r);
-          float x0, n0, d0;
-          farwing(u, q, x0, n0, d0);
-          n0 = (u >= ulo && u < uhi) ? n0 : 0.f;
-          p[0] = fmaf(n0, d0, p[0]);
-        }
-      }
-      // band rows: region test + Weideman for lanes inside |x|+y<15, far-wing formula elsewhere, window-masked.
-      // A line with y < 1 belongs to the CORE64 pass (same predicate on the same fp32 record in both passes).
-      const bool small_y = q.y < 1.0f;
-      if (z0 <= z1 && RTX_SC_ABLATE == 0) {
-        const int zb = z0 > r_lo ? z0 : r_lo, ze = z1 < r_hi - 1 ? z1 : r_hi - 1;
-        for (int r = zb; r <= ze; ++r) {
-          float* p = acc + r * 64 + lane;
-          const int i = ia + 64 * r + lane;
-          const float u = u0 + (float)(64 * r);
-          float x, num, rden;
-          farwing(u, q, x, num, rden);
-          const bool in_band = fabsf(u) <= zw_f;
-          if (CORE64 ? small_y : !small_y) {
-            // hum1_wei's switch |x|+y < 15 (:9840): fp32 decides unless a lane sits within 2e-3 of it; those
-            // lanes repeat the test exactly as the reference forms it, in fp64: x = -Im Z1 = -((sg0 - sg)*cte)
-            const float s32 = fabsf(x) + q.y;
-            bool wz = s32 < 15.0f;
-            const bool near = fabsf(s32 - 15.0f) < 2e-3f;
-            if (CORE64 || __ballot(near)) {
-              const LineRec64 Q = rec64[base + slot];
-              const double sg = grid_x(a.g, a.g.offset + (long long)i);
-              const double x64 = -((Q.sg0 - sg) * Q.cte);
-              const bool wz64 = fabs(x64) + Q.y < 15.0;
-              wz = (CORE64 || near) ? wz64 : wz;
-              if (CORE64 && wz) {
-                num = (float)(Q.A * weideman_re<double>(x64, Q.y));
-                rden = 1.0f;
-              }
-            }
-            if (!CORE64 && wz) {
-              // pressure-broadened lines (y >= 6: ~70 % of the band lines of C3): the whole band has |z| >= 6 and the
-              // 6-term asymptotic series agrees with Weideman-24 to 6.4e-8; Weideman itself only for y < 6
-              if (RTX_SC_ASYM && q.y >= 6.0f) num = q.A * asym6_re(x, q.y);
-              else num = q.A * weideman_re<float>(x, q.y);
-              rden = 1.0f;
-            }
-            if (CORE64) {  // this pass adds ONLY the band lanes of small-y lines
-              num = in_band ? num : 0.f;
-              touched = true;
-            }
-          } else {
-            // the other pass owns this line's band lanes; here only the far-wing lanes of the row count
-            num = (CORE64 || in_band) ? 0.f : num;
-          }
-          num = (u >= ulo && u < uhi) ? num : 0.f;
-          p[0] = fmaf(num, rden, p[0]);
-        }
-      }
-    }
-  }
+  for (int slot = rng.x + wave; slot < rng.y; slot += 4) visit_line<CORE64, false>(a, rec, rec64, slot, acc, ia, ib, nt, lane, lanef, touched);
   __syncthreads();  // every wave's tile is complete
 
   if (CORE64) {  // did any wave add anything? (uniform per workgroup through LDS)
@@ -223,29 +301,117 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
     __syncthreads();
     if (!s_touched) return;
   }
-  // ---- fixed-order sum of the four private tiles, coalesced stores ------------------------------------
-#pragma unroll 4
-  for (int r = wave; r < ROWS; r += 4) {
-    const int t = r * 64 + lane;
-    const long long i = (long long)ia + t;
-    if (i < (long long)ib) {
-      const float v = (s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t]);
-      const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
-      if (CORE64) {
-        if (a.out32) a.out32[o] += v;
-        if (a.out64) a.out64[o] += (double)v * a.inv_scale;
-      } else {
-        if (a.out32) a.out32[o] = v;
-        if (a.out64) a.out64[o] = (double)v * a.inv_scale;
+  store_tile<CORE64, false>(a, s_acc, nullptr, k, ia, ib, wave, lane);
+}
+
+// ---- main pass, far rows at Chebyshev nodes -------------------------------------------------------------
+#define SC_NEAR_CAP 64  // per-wave list of lines that need point-by-point rows in this tile
+__global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
+  constexpr int ROWS = RTX_SC_ROWS;
+  constexpr int TILE = 64 * ROWS;
+  __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
+  __shared__ float s_nodal[4][ROWS][CHEB_N];    // per-wave sums of the far lines at the rows' Chebyshev nodes
+  __shared__ int s_near[4][SC_NEAR_CAP];
+
+  const int b = blockIdx.x;
+  const int tile = (b & 7) * a.tiles_per_xcd + (b >> 3);
+  if (tile >= a.n_tiles) return;
+  const int k = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long long n = a.g.n;
+  const int ia = tile * TILE;
+  const int ib = (int)((long long)ia + TILE < n ? (long long)ia + TILE : n);
+  const int nt = ib - ia;
+  const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
+  const LineRec64* __restrict__ rec64 = a.rec64 + (size_t)k * (size_t)a.n_lines;
+  const int2 rng = a.ranges[(size_t)k * a.n_tiles + tile];
+  float* __restrict__ acc = s_acc[wave];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r * 64 + lane] = 0.f;
+  const float lanef = (float)lane;
+  bool touched = false;
+
+  // lane = (line l of the chunk, node j)
+  const int l = lane >> 3, j = lane & 7;
+  const float off_j = CHEB_OFF[j];
+  float nod[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) nod[r] = 0.f;
+  int n_near = 0;  // wave-uniform
+  int* __restrict__ near_list = s_near[wave];
+
+  auto drain = [&]() {
+    for (int e = 0; e < n_near; ++e) {
+      const int slot = __builtin_amdgcn_readfirstlane(near_list[e]);
+      visit_line<false, true>(a, rec, rec64, slot, acc, ia, ib, nt, lane, lanef, touched);
+    }
+    n_near = 0;
+  };
+
+  // chunks of 8 candidate lines, dealt round-robin to the 4 waves in table order
+  for (int c_base = rng.x + 8 * wave; c_base < rng.y; c_base += 32) {
+    const int slot = c_base + l;
+    const bool valid = slot < rng.y;
+    const float4* __restrict__ pr = reinterpret_cast<const float4*>(rec + (valid ? slot : rng.y - 1));
+    const float4 f0 = pr[0];  // a c b1 b0
+    const float4 f1 = pr[1];  // Ay Ay0 y A
+    const float4 f2 = pr[2];  // i0 lo hi zw (int bits)
+    const int qi0 = __float_as_int(f2.x), qlo = __float_as_int(f2.y), qhi = __float_as_int(f2.z), qzw = __float_as_int(f2.w);
+    const bool reach = valid && qhi > ia && qlo < ib;
+    const RowGeom g = row_geom(qi0, qlo, qhi, qzw, ia, nt);
+    // far rows: wholly inside the window and outside the near zone
+    unsigned m_in = 0u, m_near = 0u;
+    if (g.c1 > g.c0) m_in = ((1u << g.c1) - 1u) & ~((1u << g.c0) - 1u);
+    {
+      const int a0 = g.n0 > 0 ? g.n0 : 0, a1 = g.n1 < ROWS - 1 ? g.n1 : ROWS - 1;
+      if (a1 >= a0) m_near = ((1u << (a1 + 1)) - 1u) & ~((1u << a0) - 1u);
+    }
+    const unsigned m_far = reach ? (m_in & ~m_near) : 0u;
+    // point-by-point work in this tile: a near-zone row the window reaches, or a window edge
+    const int o0 = g.r_lo > g.n0 ? g.r_lo : g.n0, o1 = g.r_hi - 1 < g.n1 ? g.r_hi - 1 : g.n1;
+    const bool need_near = reach && (o0 <= o1 || g.part_l || g.part_r);
+
+    if (RTX_SC_ABLATE != 3 && __ballot(m_far != 0u)) {
+      const float ub = (float)(ia - qi0);           // integer-valued
+      const float cj = fmaf(off_j, f0.x, f0.y);     // x at (row start + node offset) relative to u = 0
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const float x = fmaf(ub + (float)(64 * r), f0.x, cj);
+        const float xx = x * x;
+        float num = fmaf(xx, f1.x, f1.y);
+        const float rden = __builtin_amdgcn_rcpf(fmaf(xx + f0.z, xx, f0.w));
+        num = __int_as_float(__float_as_int(num) & __builtin_amdgcn_sbfe((int)m_far, r, 1));
+        nod[r] = fmaf(num, rden, nod[r]);
       }
     }
+    const unsigned long long nb = __ballot(need_near && j == 0);
+    if (nb) {
+      if (need_near && j == 0) near_list[n_near + __popcll(nb & ((1ull << lane) - 1ull))] = slot;
+      n_near += __popcll(nb);
+      if (n_near > SC_NEAR_CAP - 8) drain();
+    }
   }
+  drain();
+
+  // sum the 8 line slots of each node (lanes l = 0..7 of equal j), one copy per wave
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    float v = nod[r];
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane < 8) s_nodal[wave][r][lane] = v;
+  }
+  __syncthreads();
+  store_tile<false, true>(a, s_acc, s_nodal, k, ia, ib, wave, lane);
 }
 
 extern "C" int rtx_voigt_scatter_tile_points(void) { return 64 * RTX_SC_ROWS; }
 
 int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64, int64_t ld,
-                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t)) {
+                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t),
+                          int nodal) {
   constexpr int TILE = 64 * RTX_SC_ROWS;
   const long long n_tiles_ll = (grid->n + TILE - 1) / TILE;
   if (n_tiles_ll > P->max_tiles) RTX_FAIL("grid shard of %lld points exceeds the prep capacity", (long long)grid->n);
@@ -257,7 +423,8 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   a.n_tiles = n_tiles; a.tiles_per_xcd = (n_tiles + 7) / 8;
   a.g = to_dev(grid);
   a.out32 = out_f32; a.out64 = out_f64; a.ld = ld; a.inv_scale = 1.0 / P->scale;
-  hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   hipLaunchKernelGGL((voigt_scatter_kernel<true>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
