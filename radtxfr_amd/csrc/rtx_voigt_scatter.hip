@@ -97,6 +97,50 @@ __device__ __forceinline__ RowGeom row_geom(int qi0, int qlo, int qhi, int qzw, 
   return g;
 }
 
+// One band row: region test + Weideman for lanes inside |x|+y<15, far-wing formula elsewhere, window-masked.
+// A line with y < 1 belongs to the CORE64 pass (same predicate on the same fp32 record in both passes).
+// The record fields may live in SGPRs (scalar visit) or be wave-uniform VGPR values (nodal kernel).
+template <bool CORE64>
+__device__ __forceinline__ void band_row(const ScArgs& a, const LineRec64* __restrict__ rec64, int slot, const LineRec& q, float u, int i,
+                                         float zw_f, float ulo, float uhi, bool small_y, float& num, float& rden, bool& touched) {
+  float x;
+  farwing(u, q, x, num, rden);
+  const bool in_band = fabsf(u) <= zw_f;
+  if (CORE64 ? small_y : !small_y) {
+    // hum1_wei's switch |x|+y < 15 (:9840): fp32 decides unless a lane sits within 2e-3 of it; those
+    // lanes repeat the test exactly as the reference forms it, in fp64: x = -Im Z1 = -((sg0 - sg)*cte)
+    const float s32 = fabsf(x) + q.y;
+    bool wz = s32 < 15.0f;
+    const bool near = fabsf(s32 - 15.0f) < 2e-3f;
+    if (CORE64 || __ballot(near)) {
+      const LineRec64 Q = rec64[slot];
+      const double sg = grid_x(a.g, a.g.offset + (long long)i);
+      const double x64 = -((Q.sg0 - sg) * Q.cte);
+      const bool wz64 = fabs(x64) + Q.y < 15.0;
+      wz = (CORE64 || near) ? wz64 : wz;
+      if (CORE64 && wz) {
+        num = (float)(Q.A * weideman_re<double>(x64, Q.y));
+        rden = 1.0f;
+      }
+    }
+    if (!CORE64 && wz) {
+      // pressure-broadened lines (y >= 6: ~70 % of the band lines of C3): the whole band has |z| >= 6 and the
+      // 6-term asymptotic series agrees with Weideman-24 to 6.4e-8; Weideman itself only for y < 6
+      if (RTX_SC_ASYM && q.y >= 6.0f) num = q.A * asym6_re(x, q.y);
+      else num = q.A * weideman_re<float>(x, q.y);
+      rden = 1.0f;
+    }
+    if (CORE64) {  // this pass adds ONLY the band lanes of small-y lines
+      num = in_band ? num : 0.f;
+      touched = true;
+    }
+  } else {
+    // the other pass owns this line's band lanes; here only the far-wing lanes of the row count
+    num = (CORE64 || in_band) ? 0.f : num;
+  }
+  num = (u >= ulo && u < uhi) ? num : 0.f;
+}
+
 // One line, taken by one wave: point-by-point rows into the wave's LDS tile. NODAL: only the rows of the near
 // zone (the far rows were added at the Chebyshev nodes); the record arrives through scalar loads.
 template <bool CORE64, bool NODAL>
@@ -173,51 +217,13 @@ __device__ __forceinline__ void visit_line(const ScArgs& a, const LineRec* __res
       p[0] = fmaf(n0, d0, p[0]);
     }
   }
-  // band rows: region test + Weideman for lanes inside |x|+y<15, far-wing formula elsewhere, window-masked.
-  // A line with y < 1 belongs to the CORE64 pass (same predicate on the same fp32 record in both passes).
   const bool small_y = q.y < 1.0f;
   if (z0 <= z1 && (RTX_SC_ABLATE == 0 || RTX_SC_ABLATE == 3)) {
     const int zb = z0 > r_lo ? z0 : r_lo, ze = z1 < r_hi - 1 ? z1 : r_hi - 1;
     for (int r = zb; r <= ze; ++r) {
       float* p = acc + r * 64 + lane;
-      const int i = ia + 64 * r + lane;
-      const float u = u0 + (float)(64 * r);
-      float x, num, rden;
-      farwing(u, q, x, num, rden);
-      const bool in_band = fabsf(u) <= zw_f;
-      if (CORE64 ? small_y : !small_y) {
-        // hum1_wei's switch |x|+y < 15 (:9840): fp32 decides unless a lane sits within 2e-3 of it; those
-        // lanes repeat the test exactly as the reference forms it, in fp64: x = -Im Z1 = -((sg0 - sg)*cte)
-        const float s32 = fabsf(x) + q.y;
-        bool wz = s32 < 15.0f;
-        const bool near = fabsf(s32 - 15.0f) < 2e-3f;
-        if (CORE64 || __ballot(near)) {
-          const LineRec64 Q = rec64[slot];
-          const double sg = grid_x(a.g, a.g.offset + (long long)i);
-          const double x64 = -((Q.sg0 - sg) * Q.cte);
-          const bool wz64 = fabs(x64) + Q.y < 15.0;
-          wz = (CORE64 || near) ? wz64 : wz;
-          if (CORE64 && wz) {
-            num = (float)(Q.A * weideman_re<double>(x64, Q.y));
-            rden = 1.0f;
-          }
-        }
-        if (!CORE64 && wz) {
-          // pressure-broadened lines (y >= 6: ~70 % of the band lines of C3): the whole band has |z| >= 6 and the
-          // 6-term asymptotic series agrees with Weideman-24 to 6.4e-8; Weideman itself only for y < 6
-          if (RTX_SC_ASYM && q.y >= 6.0f) num = q.A * asym6_re(x, q.y);
-          else num = q.A * weideman_re<float>(x, q.y);
-          rden = 1.0f;
-        }
-        if (CORE64) {  // this pass adds ONLY the band lanes of small-y lines
-          num = in_band ? num : 0.f;
-          touched = true;
-        }
-      } else {
-        // the other pass owns this line's band lanes; here only the far-wing lanes of the row count
-        num = (CORE64 || in_band) ? 0.f : num;
-      }
-      num = (u >= ulo && u < uhi) ? num : 0.f;
+      float num, rden;
+      band_row<CORE64>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
       p[0] = fmaf(num, rden, p[0]);
     }
   }
@@ -305,13 +311,16 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 }
 
 // ---- main pass, far rows at Chebyshev nodes -------------------------------------------------------------
-#define SC_NEAR_CAP 64  // per-wave list of lines that need point-by-point rows in this tile
+// Per-wave list of the lines that need point-by-point rows in this tile. The classification lanes write a 64-B
+// entry (record fields, window in u, row masks); the consumer reads it back with broadcast LDS reads, so a line
+// costs no scalar load, no scalar geometry and its constants reach the VALU as (wave-uniform) vector operands.
+#define SC_ENT_CAP 16
 __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
   __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
   __shared__ float s_nodal[4][ROWS][CHEB_N];    // per-wave sums of the far lines at the rows' Chebyshev nodes
-  __shared__ int s_near[4][SC_NEAR_CAP];
+  __shared__ float4 s_ent[4][SC_ENT_CAP][4];
 
   const int b = blockIdx.x;
   const int tile = (b & 7) * a.tiles_per_xcd + (b >> 3);
@@ -338,15 +347,42 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   float nod[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) nod[r] = 0.f;
-  int n_near = 0;  // wave-uniform
-  int* __restrict__ near_list = s_near[wave];
+  int n_ent = 0;  // wave-uniform
+  float4(*__restrict__ ent)[4] = s_ent[wave];
 
   auto drain = [&]() {
-    for (int e = 0; e < n_near; ++e) {
-      const int slot = __builtin_amdgcn_readfirstlane(near_list[e]);
-      visit_line<false, true>(a, rec, rec64, slot, acc, ia, ib, nt, lane, lanef, touched);
+    for (int e = 0; e < n_ent; ++e) {
+      const float4 e0 = ent[e][0], e1 = ent[e][1], e2 = ent[e][2], e3 = ent[e][3];
+      LineRec q;
+      q.a = e0.x; q.c = e0.y; q.b1 = e0.z; q.b0 = e0.w;
+      q.Ay = e1.x; q.Ay0 = e1.y; q.y = e1.z; q.A = e1.w;
+      const float u0 = e2.x + lanef, ulo = e2.y, uhi = e2.z, zw_f = e2.w;
+      unsigned m_pp = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.x));
+      unsigned m_bd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.y));
+      const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(e3.z));
+      // far-wing rows, point by point, lanes outside the window masked (interior rows: mask all-true)
+      while (m_pp) {
+        const int r = __builtin_ctz(m_pp);
+        m_pp &= m_pp - 1u;
+        float* p = acc + r * 64 + lane;
+        const float u = u0 + (float)(64 * r);
+        float x0, n0, d0;
+        farwing(u, q, x0, n0, d0);
+        n0 = (u >= ulo && u < uhi) ? n0 : 0.f;
+        p[0] = fmaf(n0, d0, p[0]);
+      }
+      if (RTX_SC_ABLATE == 1 || RTX_SC_ABLATE == 2) m_bd = 0u;
+      const bool small_y = q.y < 1.0f;
+      while (m_bd) {
+        const int r = __builtin_ctz(m_bd);
+        m_bd &= m_bd - 1u;
+        float* p = acc + r * 64 + lane;
+        float num, rden;
+        band_row<false>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
+        p[0] = fmaf(num, rden, p[0]);
+      }
     }
-    n_near = 0;
+    n_ent = 0;
   };
 
   // chunks of 8 candidate lines, dealt round-robin to the 4 waves in table order
@@ -360,17 +396,17 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
     const int qi0 = __float_as_int(f2.x), qlo = __float_as_int(f2.y), qhi = __float_as_int(f2.z), qzw = __float_as_int(f2.w);
     const bool reach = valid && qhi > ia && qlo < ib;
     const RowGeom g = row_geom(qi0, qlo, qhi, qzw, ia, nt);
-    // far rows: wholly inside the window and outside the near zone
-    unsigned m_in = 0u, m_near = 0u;
-    if (g.c1 > g.c0) m_in = ((1u << g.c1) - 1u) & ~((1u << g.c0) - 1u);
-    {
-      const int a0 = g.n0 > 0 ? g.n0 : 0, a1 = g.n1 < ROWS - 1 ? g.n1 : ROWS - 1;
-      if (a1 >= a0) m_near = ((1u << (a1 + 1)) - 1u) & ~((1u << a0) - 1u);
-    }
-    const unsigned m_far = reach ? (m_in & ~m_near) : 0u;
-    // point-by-point work in this tile: a near-zone row the window reaches, or a window edge
-    const int o0 = g.r_lo > g.n0 ? g.r_lo : g.n0, o1 = g.r_hi - 1 < g.n1 ? g.r_hi - 1 : g.n1;
-    const bool need_near = reach && (o0 <= o1 || g.part_l || g.part_r);
+    // row masks: reached / wholly inside the window / near zone / band
+    auto bits = [](int lo, int hi) -> unsigned {  // rows [lo, hi), 0 <= lo, hi <= ROWS
+      return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    };
+    const unsigned m_reach = reach ? bits(g.r_lo, g.r_hi) : 0u;
+    const unsigned m_in = reach ? bits(g.c0, g.c1) : 0u;
+    const unsigned m_near = bits(g.n0 > 0 ? g.n0 : 0, (g.n1 < ROWS - 1 ? g.n1 : ROWS - 1) + 1);
+    const unsigned m_band = bits(g.z0, g.z1 + 1);
+    const unsigned m_far = m_in & ~m_near;                                   // smooth: Chebyshev nodes
+    const unsigned m_bd = m_reach & m_band;                                  // band rows
+    const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;  // near-zone rows and window edges
 
     if (RTX_SC_ABLATE != 3 && __ballot(m_far != 0u)) {
       const float ub = (float)(ia - qi0);           // integer-valued
@@ -385,11 +421,18 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
         nod[r] = fmaf(num, rden, nod[r]);
       }
     }
-    const unsigned long long nb = __ballot(need_near && j == 0);
-    if (nb) {
-      if (need_near && j == 0) near_list[n_near + __popcll(nb & ((1ull << lane) - 1ull))] = slot;
-      n_near += __popcll(nb);
-      if (n_near > SC_NEAR_CAP - 8) drain();
+    const bool emit = j == 0 && (m_pp | m_bd) != 0u;
+    const unsigned long long eb = __ballot(emit);
+    if (eb) {
+      if (emit) {
+        float4* d = ent[n_ent + __popcll(eb & ((1ull << lane) - 1ull))];
+        d[0] = f0;
+        d[1] = f1;
+        d[2] = make_float4((float)(ia - qi0), (float)(qlo - qi0), (float)(qhi - qi0), qzw > 0 ? (float)qzw : -1.0f);
+        d[3] = make_float4(__int_as_float((int)m_pp), __int_as_float((int)m_bd), __int_as_float(slot), 0.f);
+      }
+      n_ent += __popcll(eb);
+      if (n_ent > SC_ENT_CAP - 8) drain();
     }
   }
   drain();
