@@ -45,6 +45,21 @@ __device__ __forceinline__ double grid_x(const GridDev& g, long long ig) {
   return (ig == g.n_total - 1) ? g.xmax : v;
 }
 
+// ---- XCD-aware tile order of the line-sum kernels ------------------------------------------------
+// Workgroup b runs on XCD b & 7 (round-robin dispatch). An XCD walks chunks of RTX_XCD_CHUNK consecutive tiles, so
+// neighbouring tiles share their line records in that XCD's L2; the chunks are dealt round-robin over the XCDs, so
+// every XCD sees the whole spectrum. (One contiguous eighth of the spectrum per XCD left the XCD with the highest
+// wavenumbers -- widest Doppler cores, most Weideman rows -- as the straggler of every launch.)
+#define RTX_XCD_CHUNK 16
+__device__ __forceinline__ int xcd_tile(int b) {
+  const int idx = b >> 3, c = idx / RTX_XCD_CHUNK, w = idx - c * RTX_XCD_CHUNK;
+  return (c * 8 + (b & 7)) * RTX_XCD_CHUNK + w;
+}
+static inline int xcd_slots(int n_tiles) {  // block slots per XCD: grid.x = 8 * xcd_slots(n_tiles)
+  const int n_chunks = (n_tiles + RTX_XCD_CHUNK - 1) / RTX_XCD_CHUNK;
+  return ((n_chunks + 7) / 8) * RTX_XCD_CHUNK;
+}
+
 // ---- Planck radiance in fp32 from an fp64 exponent (shared by the TUD and at-sensor kernels) ----------
 // B(nu,T) in uW/(cm^2 sr cm^-1):  c1*(100 nu)^3*1e4 / (exp(c2*100 nu/T) - 1)
 __device__ __forceinline__ float planck_f32(double c1x3, double x, double c2l2e_over_T) {

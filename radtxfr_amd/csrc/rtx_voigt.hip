@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, RTX_VOIGT_WAVES) void voigt_sum_kernel(VsArgs 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD one
   // contiguous run of tiles -- neighbouring tiles share most of their line records in that XCD's L2.
   const int b = blockIdx.x;
-  const int tile = (b & 7) * a.tiles_per_xcd + (b >> 3);
+  const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
   if (tile >= a.n_tiles) return;  // whole workgroup exits together
   const int k = blockIdx.y;
   if (CORE64 && a.smally[k] == 0) return;
@@ -333,7 +333,7 @@ extern "C" int rtx_voigt_sum(const rtx_prep* P, const rtx_grid* grid, int n_laye
   RTX_LAUNCH_CHECK();
   VsArgs a;
   a.rec = P->rec; a.rec64 = P->rec64; a.ranges = P->ranges; a.smally = P->smally; a.n_lines = P->n_lines;
-  a.n_tiles = n_tiles; a.tiles_per_xcd = (n_tiles + 7) / 8;
+  a.n_tiles = n_tiles; a.tiles_per_xcd = xcd_slots(n_tiles);
   a.g = to_dev(grid);
   a.out32 = out_f32; a.out64 = out_f64; a.ld = ld; a.inv_scale = 1.0 / P->scale;
   hipLaunchKernelGGL((voigt_sum_kernel<RTX_VOIGT_P, false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);

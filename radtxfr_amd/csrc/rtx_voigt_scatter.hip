@@ -32,6 +32,7 @@
 #include "rtx_voigt_math.h"
 
 #include "cheb8_64.inc"
+#include <vector>
 
 #ifndef RTX_SC_ABLATE
 #define RTX_SC_ABLATE 0  /* timing experiments: 1 = no band rows, 2 = no band rows and no edge rows, 3 = no far rows */
@@ -47,7 +48,18 @@
 #endif
 static_assert(RTX_SC_ROWS <= 31, "row masks are 32-bit");
 
+#ifndef RTX_SC_STAMP
+#define RTX_SC_STAMP 0  /* 1: per-phase cycle totals of the nodal kernel, printed by the host after every launch (debug builds) */
+#endif
+#define SC_NSTAMP 8
+#define STAMP(i_)                                 \
+  if (RTX_SC_STAMP) {                             \
+    const long long t_now_ = (long long)clock64(); \
+    t_ph[i_] += t_now_ - t_prev;                  \
+    t_prev = t_now_;                              \
+  }
 struct ScArgs {
+  unsigned long long* stamp;
   const LineRec* rec;
   const LineRec64* rec64;
   const int2* ranges;
@@ -206,7 +218,7 @@ __device__ __forceinline__ void visit_line(const ScArgs& a, const LineRec* __res
     // partial rows (at most two) outside the band rows: far-wing formula, lanes outside [lo,hi) masked
     const int eL = g.part_l ? r_lo : -1;
     const int eR = (g.part_r && r_hi - 1 != eL) ? r_hi - 1 : -1;
-    for (int pass = 0; pass < (RTX_SC_ABLATE == 2 ? 0 : 2); ++pass) {
+    for (int pass = 0; pass < ((RTX_SC_ABLATE & 4) ? 0 : 2); ++pass) {
       const int r = pass == 0 ? eL : eR;
       if (r < 0 || (r >= z0 && r <= z1)) continue;
       float* p = acc + r * 64 + lane;
@@ -218,7 +230,7 @@ __device__ __forceinline__ void visit_line(const ScArgs& a, const LineRec* __res
     }
   }
   const bool small_y = q.y < 1.0f;
-  if (z0 <= z1 && (RTX_SC_ABLATE == 0 || RTX_SC_ABLATE == 3)) {
+  if (z0 <= z1 && !(RTX_SC_ABLATE & 1)) {
     const int zb = z0 > r_lo ? z0 : r_lo, ze = z1 < r_hi - 1 ? z1 : r_hi - 1;
     for (int r = zb; r <= ze; ++r) {
       float* p = acc + r * 64 + lane;
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
   __shared__ float s_acc[4][TILE];  // one private tile per wave
 
   const int b = blockIdx.x;
-  const int tile = (b & 7) * a.tiles_per_xcd + (b >> 3);  // XCD-aware: one contiguous run of tiles per XCD
+  const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
   if (tile >= a.n_tiles) return;
   const int k = blockIdx.y;
   if (CORE64 && a.smally[k] == 0) return;
@@ -315,15 +327,28 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 // entry (record fields, window in u, row masks); the consumer reads it back with broadcast LDS reads, so a line
 // costs no scalar load, no scalar geometry and its constants reach the VALU as (wave-uniform) vector operands.
 #define SC_ENT_CAP 16
+// tile level (32 nodes over the whole tile) needs the generated tables to match the tile length
+#ifndef SC_TILE_LEVEL
+#define SC_TILE_LEVEL (RTX_SC_ROWS == CHEB_T_ROWS)
+#endif
+#define SC_TPL (CHEB_T_N / 8)
 __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
   __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
   __shared__ float s_nodal[4][ROWS][CHEB_N];    // per-wave sums of the far lines at the rows' Chebyshev nodes
   __shared__ float4 s_ent[4][SC_ENT_CAP][4];
+#ifdef SC_PAD_LDS
+  __shared__ float s_pad[SC_PAD_LDS / 4];  // occupancy experiments
+  if (a.n_tiles < 0) s_pad[threadIdx.x] = 1.f;
+#endif
+  __shared__ float4 s_rowl[4][16][2];           // per-wave ring of lines with row-level far rows: (a c b1 b0) (Ay Ay0 ub mask)
+  // after the last drain the entry lists are dead: wave w keeps its tile-level sums in the first 128 B of its list,
+  // and the combined row-node sums [ROWS][8] live behind wave 0's
+  static_assert(CHEB_T_N * 4 + RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "aliases fit in one wave's entry list");
 
   const int b = blockIdx.x;
-  const int tile = (b & 7) * a.tiles_per_xcd + (b >> 3);
+  const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
   if (tile >= a.n_tiles) return;
   const int k = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -340,6 +365,9 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   for (int r = 0; r < ROWS; ++r) acc[r * 64 + lane] = 0.f;
   const float lanef = (float)lane;
   bool touched = false;
+  long long t_ph[SC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_prev = RTX_SC_STAMP ? (long long)clock64() : 0;
+  const long long t_begin = t_prev;
 
   // lane = (line l of the chunk, node j)
   const int l = lane >> 3, j = lane & 7;
@@ -347,7 +375,29 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   float nod[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) nod[r] = 0.f;
+  // tile level: lane (l, j) evaluates tile nodes j, j + 8, j + 16, j + 24 of line l
+  float nodT[SC_TPL], offT[SC_TPL];
+#pragma unroll
+  for (int i = 0; i < SC_TPL; ++i) {
+    nodT[i] = 0.f;
+    offT[i] = SC_TILE_LEVEL ? CHEB_T_OFF[j + 8 * i] : 0.f;
+  }
   int n_ent = 0;  // wave-uniform
+  int n_row_head = 0, n_row_tail = 0;  // wave-uniform ring indices
+  float4(*__restrict__ rowl)[2] = s_rowl[wave];
+  auto far_rows = [&](const float4 fa, const float4 fb) {  // lane (l, j): node j of the rows of ring entry l
+    const float cj = fmaf(off_j, fa.x, fa.y);  // x at (row start + node offset) relative to u = 0
+    const int mf = __float_as_int(fb.w);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const float x = fmaf(fb.z + (float)(64 * r), fa.x, cj);
+      const float xx = x * x;
+      float num = fmaf(xx, fb.x, fb.y);
+      const float rden = __builtin_amdgcn_rcpf(fmaf(xx + fa.z, xx, fa.w));
+      num = __int_as_float(__float_as_int(num) & __builtin_amdgcn_sbfe(mf, r, 1));
+      nod[r] = fmaf(num, rden, nod[r]);
+    }
+  };
   float4(*__restrict__ ent)[4] = s_ent[wave];
 
   auto drain = [&]() {
@@ -360,6 +410,7 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
       unsigned m_pp = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.x));
       unsigned m_bd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.y));
       const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(e3.z));
+      STAMP(3);  // entry read
       // far-wing rows, point by point, lanes outside the window masked (interior rows: mask all-true)
       while (m_pp) {
         const int r = __builtin_ctz(m_pp);
@@ -371,7 +422,8 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
         n0 = (u >= ulo && u < uhi) ? n0 : 0.f;
         p[0] = fmaf(n0, d0, p[0]);
       }
-      if (RTX_SC_ABLATE == 1 || RTX_SC_ABLATE == 2) m_bd = 0u;
+      STAMP(4);  // pp rows
+      if (RTX_SC_ABLATE & 1) m_bd = 0u;
       const bool small_y = q.y < 1.0f;
       while (m_bd) {
         const int r = __builtin_ctz(m_bd);
@@ -381,6 +433,7 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
         band_row<false>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
         p[0] = fmaf(num, rden, p[0]);
       }
+      STAMP(5);  // band rows
     }
     n_ent = 0;
   };
@@ -404,24 +457,48 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
     const unsigned m_in = reach ? bits(g.c0, g.c1) : 0u;
     const unsigned m_near = bits(g.n0 > 0 ? g.n0 : 0, (g.n1 < ROWS - 1 ? g.n1 : ROWS - 1) + 1);
     const unsigned m_band = bits(g.z0, g.z1 + 1);
-    const unsigned m_far = m_in & ~m_near;                                   // smooth: Chebyshev nodes
+    // tile level: the window covers the whole tile and the near zone (centre +- SC_NEAR rows, band) lies outside it
+    const bool is_t = SC_TILE_LEVEL && reach && qlo <= ia && qhi - ia >= nt && (g.n1 < 0 || g.n0 >= ROWS);
+    const unsigned m_far = is_t ? 0u : (m_in & ~m_near);                     // smooth: Chebyshev nodes of the rows
     const unsigned m_bd = m_reach & m_band;                                  // band rows
     const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;  // near-zone rows and window edges
+    if (RTX_SC_STAMP && __ballot(m_pp == 0xffffffffu)) t_ph[7] += 1;  // (forces the masks, i.e. the record loads, before the stamp)
+    STAMP(0);  // record loads + geometry
 
-    if (RTX_SC_ABLATE != 3 && __ballot(m_far != 0u)) {
-      const float ub = (float)(ia - qi0);           // integer-valued
-      const float cj = fmaf(off_j, f0.x, f0.y);     // x at (row start + node offset) relative to u = 0
+    const float ub = (float)(ia - qi0);  // integer-valued
+    if (SC_TILE_LEVEL && !(RTX_SC_ABLATE & 2) && __ballot(is_t)) {
+      const int t_mask = is_t ? -1 : 0;
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        const float x = fmaf(ub + (float)(64 * r), f0.x, cj);
+      for (int i = 0; i < SC_TPL; ++i) {
+        const float x = fmaf(ub, f0.x, fmaf(offT[i], f0.x, f0.y));
         const float xx = x * x;
         float num = fmaf(xx, f1.x, f1.y);
         const float rden = __builtin_amdgcn_rcpf(fmaf(xx + f0.z, xx, f0.w));
-        num = __int_as_float(__float_as_int(num) & __builtin_amdgcn_sbfe((int)m_far, r, 1));
-        nod[r] = fmaf(num, rden, nod[r]);
+        num = __int_as_float(__float_as_int(num) & t_mask);
+        nodT[i] = fmaf(num, rden, nodT[i]);
       }
     }
-    const bool emit = j == 0 && (m_pp | m_bd) != 0u;
+    // lines with row-level far rows go through a per-wave ring so that the 20-row evaluation always runs on 8 such
+    // lines at once (edge lines are scattered through the table order: evaluated in place they would drag nearly
+    // every step through the row loop for one or two useful lanes)
+    {
+      const bool push = !(RTX_SC_ABLATE & 2) && j == 0 && m_far != 0u;
+      const unsigned long long pb = __ballot(push);
+      if (pb) {
+        if (push) {
+          float4* d = rowl[(n_row_tail + __popcll(pb & ((1ull << lane) - 1ull))) & 15];
+          d[0] = f0;
+          d[1] = make_float4(f1.x, f1.y, ub, __int_as_float((int)m_far));
+        }
+        n_row_tail += __popcll(pb);
+        if (n_row_tail - n_row_head >= 8) {
+          far_rows(rowl[(n_row_head + l) & 15][0], rowl[(n_row_head + l) & 15][1]);
+          n_row_head += 8;
+        }
+      }
+    }
+    STAMP(1);  // far rows
+    const bool emit = !(RTX_SC_ABLATE & 8) && j == 0 && (m_pp | m_bd) != 0u;
     const unsigned long long eb = __ballot(emit);
     if (eb) {
       if (emit) {
@@ -432,10 +509,19 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
         d[3] = make_float4(__int_as_float((int)m_pp), __int_as_float((int)m_bd), __int_as_float(slot), 0.f);
       }
       n_ent += __popcll(eb);
+      STAMP(2);  // emission
       if (n_ent > SC_ENT_CAP - 8) drain();
     }
   }
   drain();
+  if (n_row_tail != n_row_head) {  // the last, partial batch: empty slots get a zero mask
+    float4 fa = rowl[(n_row_head + l) & 15][0], fb = rowl[(n_row_head + l) & 15][1];
+    if (n_row_head + l >= n_row_tail) {  // never written: benign operands (den = 1), zero mask
+      fa = make_float4(0.f, 0.f, 0.f, 1.f);
+      fb = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    far_rows(fa, fb);
+  }
 
   // sum the 8 line slots of each node (lanes l = 0..7 of equal j), one copy per wave
 #pragma unroll
@@ -446,8 +532,70 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
     v += __shfl_xor(v, 32);
     if (lane < 8) s_nodal[wave][r][lane] = v;
   }
+#pragma unroll
+  for (int i = 0; i < SC_TPL; ++i) {
+    float v = nodT[i];
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (SC_TILE_LEVEL && lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[lane + 8 * i] = v;
+  }
+  STAMP(2);
   __syncthreads();
-  store_tile<false, true>(a, s_acc, s_nodal, k, ia, ib, wave, lane);
+  STAMP(6);  // barrier
+  const float* nT0 = reinterpret_cast<const float*>(&s_ent[0][0][0]);
+  const float* nT1 = reinterpret_cast<const float*>(&s_ent[1][0][0]);
+  const float* nT2 = reinterpret_cast<const float*>(&s_ent[2][0][0]);
+  const float* nT3 = reinterpret_cast<const float*>(&s_ent[3][0][0]);
+  float(*s_nodsum)[CHEB_N] = reinterpret_cast<float(*)[CHEB_N]>(reinterpret_cast<float*>(&s_ent[0][0][0]) + CHEB_T_N);
+  // stage 1: thread (r, jj) gathers the four waves' row-level sums and carries the tile-level sums to its row node
+  if (threadIdx.x < ROWS * CHEB_N) {
+    const int r = threadIdx.x >> 3, jj = threadIdx.x & 7;
+    float v = (s_nodal[0][r][jj] + s_nodal[1][r][jj]) + (s_nodal[2][r][jj] + s_nodal[3][r][jj]);
+    if (SC_TILE_LEVEL) {
+      const float4* __restrict__ m1 = reinterpret_cast<const float4*>(CHEB_T_M1[threadIdx.x]);
+      float f = 0.f;
+#pragma unroll
+      for (int m = 0; m < CHEB_T_N / 4; ++m) {
+        const float4 w = m1[m];
+        const int c = 4 * m;
+        f = fmaf(w.x, (nT0[c] + nT1[c]) + (nT2[c] + nT3[c]), f);
+        f = fmaf(w.y, (nT0[c + 1] + nT1[c + 1]) + (nT2[c + 1] + nT3[c + 1]), f);
+        f = fmaf(w.z, (nT0[c + 2] + nT1[c + 2]) + (nT2[c + 2] + nT3[c + 2]), f);
+        f = fmaf(w.w, (nT0[c + 3] + nT1[c + 3]) + (nT2[c + 3] + nT3[c + 3]), f);
+      }
+      v += f;
+    }
+    s_nodsum[r][jj] = v;
+  }
+  __syncthreads();
+  // stage 2: row nodes -> grid points, plus the four point-by-point copies; coalesced stores
+  {
+    float wl[CHEB_N];
+#pragma unroll
+    for (int jj = 0; jj < CHEB_N; ++jj) wl[jj] = CHEB_W[lane][jj];
+#pragma unroll 4
+    for (int r = wave; r < ROWS; r += 4) {
+      const int t = r * 64 + lane;
+      const long long i = (long long)ia + t;
+      float f = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < CHEB_N; ++jj) f = fmaf(wl[jj], s_nodsum[r][jj], f);
+      const float v = ((s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t])) + f;
+      if (i < (long long)ib) {
+        const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
+        if (a.out32) a.out32[o] = v;
+        if (a.out64) a.out64[o] = (double)v * a.inv_scale;
+      }
+    }
+  }
+  if (RTX_SC_STAMP) {
+    t_ph[7] = (long long)clock64() - t_begin;  // lifetime
+    if (lane == 0) {
+      unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * SC_NSTAMP;
+      for (int i = 0; i < SC_NSTAMP; ++i) o[i] = (unsigned long long)t_ph[i];
+    }
+  }
 }
 
 extern "C" int rtx_voigt_scatter_tile_points(void) { return 64 * RTX_SC_ROWS; }
@@ -463,12 +611,37 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   RTX_LAUNCH_CHECK();
   ScArgs a;
   a.rec = P->rec; a.rec64 = P->rec64; a.ranges = P->ranges; a.smally = P->smally; a.n_lines = P->n_lines;
-  a.n_tiles = n_tiles; a.tiles_per_xcd = (n_tiles + 7) / 8;
+  a.n_tiles = n_tiles; a.tiles_per_xcd = xcd_slots(n_tiles);
   a.g = to_dev(grid);
   a.out32 = out_f32; a.out64 = out_f64; a.ld = ld; a.inv_scale = 1.0 / P->scale;
+  a.stamp = nullptr;
+#if RTX_SC_STAMP
+  static unsigned long long* d_stamp = nullptr;
+  static size_t stamp_cap = 0;
+  const size_t n_stamp = (size_t)8 * a.tiles_per_xcd * n_layers * 4 * SC_NSTAMP;
+  if (stamp_cap < n_stamp) {
+    if (d_stamp) RTX_HIP(hipFree(d_stamp));
+    RTX_HIP(hipMalloc(&d_stamp, n_stamp * sizeof(unsigned long long)));
+    stamp_cap = n_stamp;
+  }
+  RTX_HIP(hipMemsetAsync(d_stamp, 0, n_stamp * sizeof(unsigned long long), st));
+  a.stamp = d_stamp;
+#endif
   if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
+#if RTX_SC_STAMP
+  {
+    std::vector<unsigned long long> hbuf(n_stamp);
+    RTX_HIP(hipMemcpyAsync(hbuf.data(), d_stamp, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RTX_HIP(hipStreamSynchronize(st));
+    double h[SC_NSTAMP] = {0};
+    for (size_t i = 0; i < n_stamp; ++i) h[i % SC_NSTAMP] += (double)hbuf[i];
+    const double w = 4.0 * 8 * a.tiles_per_xcd * n_layers;
+    fprintf(stderr, "[stamp] per wave (s_memtime ticks): load+geom %.0f far %.0f emit %.0f entry %.0f pp %.0f band %.0f barrier %.0f life %.0f\n",
+            h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
+  }
+#endif
   hipLaunchKernelGGL((voigt_scatter_kernel<true>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   return 0;
