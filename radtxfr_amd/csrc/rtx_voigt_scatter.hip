@@ -336,16 +336,13 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
   __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
-  __shared__ float s_nodal[4][ROWS][CHEB_N];    // per-wave sums of the far lines at the rows' Chebyshev nodes
   __shared__ float4 s_ent[4][SC_ENT_CAP][4];
-#ifdef SC_PAD_LDS
-  __shared__ float s_pad[SC_PAD_LDS / 4];  // occupancy experiments
-  if (a.n_tiles < 0) s_pad[threadIdx.x] = 1.f;
-#endif
   __shared__ float4 s_rowl[4][16][2];           // per-wave ring of lines with row-level far rows: (a c b1 b0) (Ay Ay0 ub mask)
   // after the last drain the entry lists are dead: wave w keeps its tile-level sums in the first 128 B of its list,
   // and the combined row-node sums [ROWS][8] live behind wave 0's
+  // [0,128) B of its entry list, its row-level sums [ROWS][8] behind them; the combined row-node sums live in the rings
   static_assert(CHEB_T_N * 4 + RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "aliases fit in one wave's entry list");
+  static_assert(RTX_SC_ROWS * CHEB_N * 4 <= 4 * 16 * 2 * 16, "combined sums fit in the rings");
 
   const int b = blockIdx.x;
   const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
@@ -412,6 +409,7 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
       const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(e3.z));
       STAMP(3);  // entry read
       // far-wing rows, point by point, lanes outside the window masked (interior rows: mask all-true)
+      if (RTX_SC_ABLATE & 4) m_pp = 0u;
       while (m_pp) {
         const int r = __builtin_ctz(m_pp);
         m_pp &= m_pp - 1u;
@@ -530,7 +528,7 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
     v += __shfl_xor(v, 8);
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if (lane < 8) s_nodal[wave][r][lane] = v;
+    if (lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[CHEB_T_N + r * CHEB_N + lane] = v;
   }
 #pragma unroll
   for (int i = 0; i < SC_TPL; ++i) {
@@ -547,11 +545,12 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   const float* nT1 = reinterpret_cast<const float*>(&s_ent[1][0][0]);
   const float* nT2 = reinterpret_cast<const float*>(&s_ent[2][0][0]);
   const float* nT3 = reinterpret_cast<const float*>(&s_ent[3][0][0]);
-  float(*s_nodsum)[CHEB_N] = reinterpret_cast<float(*)[CHEB_N]>(reinterpret_cast<float*>(&s_ent[0][0][0]) + CHEB_T_N);
+  float(*s_nodsum)[CHEB_N] = reinterpret_cast<float(*)[CHEB_N]>(&s_rowl[0][0][0]);
   // stage 1: thread (r, jj) gathers the four waves' row-level sums and carries the tile-level sums to its row node
   if (threadIdx.x < ROWS * CHEB_N) {
     const int r = threadIdx.x >> 3, jj = threadIdx.x & 7;
-    float v = (s_nodal[0][r][jj] + s_nodal[1][r][jj]) + (s_nodal[2][r][jj] + s_nodal[3][r][jj]);
+    const int o = CHEB_T_N + threadIdx.x;  // = CHEB_T_N + r * CHEB_N + jj
+    float v = (nT0[o] + nT1[o]) + (nT2[o] + nT3[o]);
     if (SC_TILE_LEVEL) {
       const float4* __restrict__ m1 = reinterpret_cast<const float4*>(CHEB_T_M1[threadIdx.x]);
       float f = 0.f;
@@ -591,6 +590,8 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   }
   if (RTX_SC_STAMP) {
     t_ph[7] = (long long)clock64() - t_begin;  // lifetime
+    t_ph[6] = t_begin;                          // absolute start (replaces the barrier bucket in the dump)
+    t_ph[2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);  // HW_ID | XCC_ID << 32
     if (lane == 0) {
       unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * SC_NSTAMP;
       for (int i = 0; i < SC_NSTAMP; ++i) o[i] = (unsigned long long)t_ph[i];
@@ -627,7 +628,10 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   RTX_HIP(hipMemsetAsync(d_stamp, 0, n_stamp * sizeof(unsigned long long), st));
   a.stamp = d_stamp;
 #endif
-  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  // RADTXFR_DEBUG_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, to time the kernel at reduced occupancy
+  static int lds_pad = -1;
+  if (lds_pad < 0) { const char* e = getenv("RADTXFR_DEBUG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
   else hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
 #if RTX_SC_STAMP
@@ -635,6 +639,10 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
     std::vector<unsigned long long> hbuf(n_stamp);
     RTX_HIP(hipMemcpyAsync(hbuf.data(), d_stamp, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     RTX_HIP(hipStreamSynchronize(st));
+    if (const char* fn = getenv("RADTXFR_STAMP_FILE")) {
+      FILE* fh = fopen(fn, "wb");
+      if (fh) { fwrite(hbuf.data(), sizeof(unsigned long long), n_stamp, fh); fclose(fh); }
+    }
     double h[SC_NSTAMP] = {0};
     for (size_t i = 0; i < n_stamp; ++i) h[i % SC_NSTAMP] += (double)hbuf[i];
     const double w = 4.0 * 8 * a.tiles_per_xcd * n_layers;
