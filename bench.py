@@ -220,7 +220,7 @@ def main():
                        "n_wavenumbers": N_WAVENUMBERS, "n_layers": N_LAYERS, "n_lines": N_LINES, "n_angles": 30,
                        "line_table": "synthetic HITRAN-format H2O+CO2, seed 20261005",
                        "parallelism": f"wavenumber-sharded x{world}" + (" + 1 RCCL all-gather" if world > 1 else "")},
-            "roofline": {"kernel": "voigt_scatter_kernel<false>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "voigt_nodal_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (cand[-1] if traffic is not None else None),
                          "ms_per_launch": ms_voigt, "algorithmic_bytes_per_launch": alg_bytes,

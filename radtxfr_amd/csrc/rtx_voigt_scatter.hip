@@ -329,9 +329,18 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #define SC_ENT_CAP 16
 // tile level (32 nodes over the whole tile) needs the generated tables to match the tile length
 #ifndef SC_TILE_LEVEL
-#define SC_TILE_LEVEL (RTX_SC_ROWS == CHEB_T_ROWS)
+#define SC_TILE_LEVEL (RTX_SC_ROWS == 12 || RTX_SC_ROWS == 16 || RTX_SC_ROWS == 20 || RTX_SC_ROWS == 24)
 #endif
 #define SC_TPL (CHEB_T_N / 8)
+#define SC_CAT_(a_, b_) a_##b_
+#define SC_CAT(a_, b_) SC_CAT_(a_, b_)
+#if SC_TILE_LEVEL
+#define CHEB_T_OFF SC_CAT(CHEB_T_OFF_, RTX_SC_ROWS)
+#define CHEB_T_M1 SC_CAT(CHEB_T_M1_, RTX_SC_ROWS)
+#else
+#define CHEB_T_OFF CHEB_T_OFF_20
+#define CHEB_T_M1 CHEB_T_M1_20
+#endif
 __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
