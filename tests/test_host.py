@@ -170,3 +170,50 @@ def test_hitran_par_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         q.write_text("too short\n")
         hitran_par.read_par(str(q))
+
+
+def test_chebyshev_tables_match_generator_and_error_bounds():
+    """cheb8_64.inc (the line-sum's node tables) is what tools/gen_cheb.py writes, and the two interpolation levels
+    keep a Lorentzian wing to ~1e-8 of itself at the distances the kernel uses them."""
+    import re
+
+    inc = open(os.path.join(ROOT, "radtxfr_amd", "csrc", "cheb8_64.inc")).read()
+    off = np.array([float(v.rstrip("f")) for v in re.search(r"CHEB_OFF\[8\] = \{([^}]*)\}", inc).group(1).split(",")])
+    k = np.arange(8)
+    nodes = 31.5 + 32.0 * np.cos((2 * k + 1) * np.pi / 16)
+    assert np.allclose(off, nodes, rtol=1e-7)
+
+    def lagr(nd, xs):
+        W = np.ones((len(xs), len(nd)))
+        for j in range(len(nd)):
+            for m in range(len(nd)):
+                if m != j:
+                    W[:, j] *= (xs - nd[m]) / (nd[j] - nd[m])
+        return W
+
+    p = np.arange(64.0)
+    W = lagr(nodes, p)
+    # row level: centre >= 3 full rows + 1 point before the row start (SC_NEAR = 3)
+    worst = 0.0
+    for g in (0.5, 5.0, 30.0, 100.0):
+        for d0 in (193.0, 225.0, 256.0):
+            f = lambda t: 1.0 / ((t + d0) ** 2 + g * g)
+            worst = max(worst, np.max(np.abs(W @ f(nodes) - f(p)) / f(p)))
+    assert worst < 2e-8, worst
+    # tile level (20 rows): pole >= 193 points outside the tile, through both stages
+    rows, nt = 20, 32
+    tile = 64 * rows
+    tn = 0.5 * (tile - 1) + 0.5 * tile * np.cos((2 * np.arange(nt) + 1) * np.pi / (2 * nt))
+    t_off = np.array([float(v.rstrip("f")) for v in re.search(r"CHEB_T_OFF_20\[32\] = \{([^}]*)\}", inc).group(1).split(",")])
+    assert np.allclose(t_off, tn, rtol=1e-7)
+    rn = np.concatenate([64.0 * r + nodes for r in range(rows)])
+    M1 = lagr(tn, rn)
+    xs = np.arange(float(tile))
+    worst = 0.0
+    for g in (0.5, 5.0, 30.0, 100.0):
+        for c in (-193.0, tile - 1 + 193.0):
+            f = lambda t: 1.0 / ((t - c) ** 2 + g * g)
+            rv = M1 @ f(tn)
+            full = np.concatenate([W @ rv[8 * r:8 * r + 8] for r in range(rows)])
+            worst = max(worst, np.max(np.abs(full - f(xs)) / f(xs)))
+    assert worst < 3e-8, worst
