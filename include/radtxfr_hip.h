@@ -209,6 +209,24 @@ int rtx_pixel_cube(int nB, int Q, const double* centre, const double* sigma, dou
                    const float* AB, int nEnd, int64_t nPix, int nMix, const int32_t* kidx,
                    const float* frac, const double* Tpix, float* cube, void* stream);
 
+/* ---- post-processing of TUD products: smooth / reduceResolution ---------------------
+ * Replaces radiative_transfer.py:1266-1324 (smooth: reflect-padded window convolution) and :1327-1350
+ * (reduceResolution: symmetrised smoothing + scipy cubic interp1d onto a coarser axis).
+ *   rtx_fir_reflect: out[r][i] = sum_k taps_h[k] * in[r][R(i + k - centre)], i in [0,n), fp64 accumulation;
+ *       R reflects about the first and last sample (j<0 -> -j, j>=n -> 2(n-1)-j), the reference's padding (:1314).
+ *       in: [n_rows][ld_in] float32 (in_is_f64 = 0) or float64 (1), device; taps_h: n_taps doubles on the HOST
+ *       (n_taps <= 8192, n_taps - 1 <= n); out: [n_rows][ld_out] float64, device.
+ *   rtx_cubic_resample: the cubic spline through ALL samples of a uniform axis x0 + i*h, evaluated at x_out
+ *       (device, fp64): in the interior scipy's not-a-knot interp1d(kind='cubic') is the cardinal cubic spline,
+ *       whose coefficients are the samples filtered by sqrt(3)*(sqrt(3)-2)^|k|; truncated at |k| <= 40 (1e-23).
+ *       Every x_out must lie in [x0 + 25 h, x0 + (n - 27) h] (error otherwise: the end conditions of the
+ *       reference's spline, whose influence decays as 0.268^k, are not reproduced; at 25 knots it is 5e-15). Ysm: [n_rows][ld] float64; out: [n_rows][ld_out] float64. */
+int rtx_fir_reflect(const void* in, int in_is_f64, int64_t ld_in, int n_rows, int64_t n,
+                    const double* taps_h, int n_taps, int centre, double* out, int64_t ld_out,
+                    void* stream);
+int rtx_cubic_resample(const double* Ysm, int64_t ld, int n_rows, int64_t n, double x0, double h,
+                       const double* x_out, int64_t n_out, double* out, int64_t ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

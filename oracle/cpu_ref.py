@@ -497,3 +497,51 @@ def compute_TUD(tbl, Xmin, Xmax, DVOUT, Zs, Ts, Ps, PLs, MFs_VAL, MFs_ID, Altitu
     if return_layers:
         return X, tau, Lu, Ld, OD
     return X, tau, Lu, Ld
+
+
+# ---- post-processing of TUD products ----------------------------------------
+def smooth(x, window_len=11, window="hanning"):
+    """radiative_transfer.py:1266-1324: reflect-pad by window_len-1 samples, convolve with the normalised
+    window ('valid'), cut back to len(x). For an even window_len the result is half a sample off centre."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim != 1 or x.size < window_len or window_len < 3:
+        return x
+    if window not in ("flat", "hanning", "hamming", "bartlett", "blackman"):
+        return x
+    s = np.r_[x[window_len - 1:0:-1], x, x[-2:-window_len - 1:-1]]  # :1314
+    w = np.ones(window_len, "d") if window == "flat" else getattr(np, window)(window_len)
+    y = np.convolve(w / w.sum(), s, mode="valid")
+    ix0 = int(np.ceil(window_len / 2 - 1))
+    ix1 = -int(np.floor(window_len / 2))
+    return y[ix0:ix1]
+
+
+def smooth_sym(y, window_len, window="hanning"):
+    """The symmetrised smoother of reduceResolution (:1331): mean of smoothing y and smoothing y reversed."""
+    return 0.5 * (smooth(y, window_len, window) + smooth(y[::-1], window_len, window)[::-1])
+
+
+def reduceResolution(X, Y, dX, N=4, window="hanning", X_out=None):
+    """radiative_transfer.py:1327-1350 (np.int -> int): symmetric window smoothing over round(dX/dX_in) samples,
+    then scipy's cubic interp1d (a not-a-knot cubic spline through ALL smoothed samples) evaluated on
+    X_out = linspace(X_[smFactor], X_[-smFactor-1], ceil(N*span/dX)+1)."""
+    import scipy.interpolate
+
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    dX_in = np.mean(np.diff(X))
+    smFactor = int(np.round(dX / dX_in))
+    sm = lambda y: smooth_sym(y, smFactor, window)
+    interp = lambda x, y, x0: scipy.interpolate.interp1d(x, y, kind="cubic", bounds_error=False, fill_value="extrapolate")(x0)
+    X_ = sm(X)
+    nPts = int(np.ceil(N * (X_[-smFactor - 1] - X_[smFactor]) / dX)) + 1
+    ret_x = X_out is None
+    if ret_x:
+        X_out = np.linspace(X_[smFactor], X_[-smFactor - 1], nPts)
+    if Y.ndim > 1:
+        Y_out = np.zeros((X_out.size, Y.shape[-1]))
+        for ii in range(Y.shape[-1]):
+            Y_out[:, ii] = interp(X_, sm(Y[:, ii]), X_out)
+    else:
+        Y_out = interp(X_, sm(Y), X_out)
+    return (X_out, Y_out) if ret_x else Y_out

@@ -33,6 +33,31 @@ def save(name, **arrs):
     print("%-28s %8.1f KB" % (name, os.path.getsize(p) / 1024))
 
 
+def make_g9(rt):
+    # ---- G9 smooth / reduceResolution (np.int restored for the call, NumPy >= 1.24 removed it) ----
+    rng = np.random.default_rng(20261009)
+    Xf = np.linspace(900.0, 904.0, 8001)  # 0.0005 cm^-1
+    base = 1.0 + 0.5 * np.sin(7.0 * Xf) + 0.2 * np.cos(91.0 * Xf)
+    for c0, wd in ((900.7, 0.004), (901.9, 0.02), (902.05, 0.0012), (903.3, 0.05)):
+        base = base + 3.0 * wd * wd / ((Xf - c0) ** 2 + wd * wd)
+    Y1 = base + 0.01 * rng.standard_normal(Xf.size)
+    Y2 = np.stack([Y1, np.exp(-Y1), Y1[::-1] ** 2], axis=1)
+    had = hasattr(np, "int")
+    if not had:
+        np.int = int
+    try:
+        sm11 = rt.smooth(Y1, 11, "hanning")
+        sm50 = rt.smooth(Y1, 50, "hamming")
+        smflat = rt.smooth(Y1, 7, "flat")
+        Xo, Yo1 = rt.reduceResolution(Xf, Y1, 0.05)
+        Yo2 = rt.reduceResolution(Xf, Y2, 0.05, X_out=Xo)
+        Xo8, Yo8 = rt.reduceResolution(Xf, Y1, 0.02, N=8, window="blackman")
+    finally:
+        if not had:
+            del np.int
+    save("g9_reduce.npz", Xf=Xf, Y1=Y1, Y2=Y2, sm11=sm11, sm50=sm50, smflat=smflat, Xo=Xo, Yo1=Yo1, Yo2=Yo2, Xo8=Xo8, Yo8=Yo8)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rt, hapi, ils_gauss = load()
@@ -180,6 +205,12 @@ def main():
     save("g7_ils.npz", X_lo=740.0, X_hi=1340.0, X_n=24000, Y2=Y2.astype(np.float64), xo1=xo1, yo1=yo1, xo2=xo2,
          yo2=yo2, xo3=xo3, yo3=yo3, yo4=yo4, xg1=xg1, yg1=yg1, xg2=xg2, yg2=yg2)
 
+    make_g9(rt)
+
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["g9"]:  # regenerate only the newest fixture
+        os.makedirs(OUT, exist_ok=True)
+        make_g9(load()[0])
+    else:
+        main()

@@ -1,0 +1,153 @@
+// smooth / reduceResolution (radiative_transfer.py:1266-1350): the post-processing step right after compute_TUD in
+// the reference's main caller (Generate_LWIR_TUD.py:82-85,124-126). Two streaming kernels, fp64 like the reference.
+#include "rtx_common.h"
+
+#define FIR_MAX_TAPS 8192
+#define FIR_BLOCK 256
+#define FIR_PER_THREAD 4
+#define FIR_TILE (FIR_BLOCK * FIR_PER_THREAD)
+#define FIR_CHUNK 512  // taps staged per pass: LDS = (FIR_TILE + FIR_CHUNK) * 8 + FIR_CHUNK * 8 = 16 KiB
+
+// out[r][i] = sum_k taps[k] * in[r][R(i + k - centre)]. A workgroup owns FIR_TILE consecutive outputs of one row and
+// walks the taps in chunks: the input span of a chunk and the chunk's taps are staged in LDS (the reflection is
+// applied while staging), each thread keeps FIR_PER_THREAD running sums and slides a register window over the span:
+// per tap one broadcast LDS read (the tap) and one LDS read (the newest sample) feed FIR_PER_THREAD fp64 FMAs.
+template <typename T>
+__global__ __launch_bounds__(FIR_BLOCK) void fir_reflect_kernel(const T* __restrict__ in, long long ld_in, long long n,
+                                                                const double* __restrict__ taps, int n_taps, int centre,
+                                                                double* __restrict__ out, long long ld_out) {
+  __shared__ double s_x[FIR_TILE + FIR_CHUNK];
+  __shared__ double s_t[FIR_CHUNK];
+  const int row = blockIdx.y;
+  const long long i0 = (long long)blockIdx.x * FIR_TILE;
+  const T* __restrict__ src = in + (size_t)row * (size_t)ld_in;
+  double acc[FIR_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < FIR_PER_THREAD; ++j) acc[j] = 0.0;
+  const int t0 = threadIdx.x * FIR_PER_THREAD;
+  for (int k0 = 0; k0 < n_taps; k0 += FIR_CHUNK) {
+    const int kc = n_taps - k0 < FIR_CHUNK ? n_taps - k0 : FIR_CHUNK;
+    __syncthreads();
+    // samples i0 + k0 - centre + [0, FIR_TILE + kc - 1)
+    for (int s = threadIdx.x; s < FIR_TILE + kc - 1; s += FIR_BLOCK) {
+      long long jdx = i0 + k0 - centre + s;
+      if (jdx < 0) jdx = -jdx;
+      if (jdx >= n) jdx = 2 * (n - 1) - jdx;
+      jdx = jdx < 0 ? 0 : (jdx >= n ? n - 1 : jdx);  // only outputs past the end of the row can get here
+      s_x[s] = (double)src[jdx];
+    }
+    for (int s = threadIdx.x; s < kc; s += FIR_BLOCK) s_t[s] = taps[k0 + s];
+    __syncthreads();
+    double w[FIR_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < FIR_PER_THREAD - 1; ++j) w[j + 1] = s_x[t0 + j];
+    for (int k = 0; k < kc; ++k) {
+#pragma unroll
+      for (int j = 0; j < FIR_PER_THREAD - 1; ++j) w[j] = w[j + 1];
+      w[FIR_PER_THREAD - 1] = s_x[t0 + k + FIR_PER_THREAD - 1];
+      const double tk = s_t[k];
+#pragma unroll
+      for (int j = 0; j < FIR_PER_THREAD; ++j) acc[j] = fma(tk, w[j], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < FIR_PER_THREAD; ++j) {
+    const long long i = i0 + t0 + j;
+    if (i < n) out[(size_t)row * (size_t)ld_out + (size_t)i] = acc[j];
+  }
+}
+
+extern "C" int rtx_fir_reflect(const void* in, int in_is_f64, int64_t ld_in, int n_rows, int64_t n, const double* taps_h,
+                               int n_taps, int centre, double* out, int64_t ld_out, void* stream) {
+  if (!in || !taps_h || !out) RTX_FAIL("a required pointer is NULL");
+  if (n_rows < 1 || n < 1) RTX_FAIL("n_rows=%d n=%lld", n_rows, (long long)n);
+  if (n_taps < 1 || n_taps > FIR_MAX_TAPS) RTX_FAIL("n_taps=%d outside [1,%d]", n_taps, FIR_MAX_TAPS);
+  if (n_taps - 1 > n) RTX_FAIL("window of %d taps is longer than the %lld samples (one reflection only)", n_taps, (long long)n);
+  if (centre < 0 || centre >= n_taps) RTX_FAIL("centre=%d outside the %d taps", centre, n_taps);
+  if (ld_in < n || ld_out < n) RTX_FAIL("leading dimension smaller than the row");
+  if (n_rows > 65535) RTX_FAIL("n_rows=%d too large", n_rows);
+  hipStream_t st = (hipStream_t)stream;
+  double* d_taps = nullptr;
+  RTX_HIP(hipMallocAsync((void**)&d_taps, (size_t)n_taps * sizeof(double), st));
+  RTX_HIP(hipMemcpyAsync(d_taps, taps_h, (size_t)n_taps * sizeof(double), hipMemcpyHostToDevice, st));
+  RTX_HIP(hipStreamSynchronize(st));  // taps_h may be a temporary of the caller
+  const dim3 grid((unsigned)((n + FIR_TILE - 1) / FIR_TILE), (unsigned)n_rows);
+  if (in_is_f64)
+    hipLaunchKernelGGL(fir_reflect_kernel<double>, grid, dim3(FIR_BLOCK), 0, st, (const double*)in, (long long)ld_in, (long long)n, d_taps,
+                       n_taps, centre, out, (long long)ld_out);
+  else
+    hipLaunchKernelGGL(fir_reflect_kernel<float>, grid, dim3(FIR_BLOCK), 0, st, (const float*)in, (long long)ld_in, (long long)n, d_taps,
+                       n_taps, centre, out, (long long)ld_out);
+  RTX_LAUNCH_CHECK();
+  RTX_HIP(hipFreeAsync(d_taps, st));
+  return 0;
+}
+
+// Cardinal cubic spline on a uniform axis. With B-spline coefficients c = prefilter(y), prefilter taps
+// sqrt(3) z^|k|, z = sqrt(3) - 2 (the inverse of the [1 4 1]/6 sampling of the cubic B-spline), the spline at
+// t = i + f is  sum_j b_j(f) c[i - 1 + j]. One thread per (row, output point); 4 x 81 cached loads.
+#define SPL_K 40
+#define SPL_EDGE 24
+__global__ __launch_bounds__(256) void cubic_resample_kernel(const double* __restrict__ y, long long ld, long long n, double x0, double inv_h,
+                                                            const double* __restrict__ x_out, long long n_out,
+                                                            double* __restrict__ out, long long ld_out, int* __restrict__ bad) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_out) return;
+  const int row = blockIdx.y;
+  const double t = (x_out[q] - x0) * inv_h;
+  long long i = (long long)floor(t);
+  if (!(i - 1 - SPL_EDGE >= 0 && i + 2 + SPL_EDGE <= n - 1)) {  // also catches NaN
+    *bad = 1;
+    return;
+  }
+  const double f = t - (double)i;
+  const double* __restrict__ src = y + (size_t)row * (size_t)ld;
+  const long long a0 = i - 1 - SPL_K;
+  // c[j] = sum_{k=-K..K} pre[|k|] y[i-1+j+k], j = 0..3: one sweep over the 2K+4 samples
+  const double z = -0.2679491924311227;  // sqrt(3) - 2
+  double pre[SPL_K + 1];
+  pre[0] = 1.7320508075688772;
+#pragma unroll
+  for (int k = 1; k <= SPL_K; ++k) pre[k] = pre[k - 1] * z;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+  for (int s = 0; s < 2 * SPL_K + 4; ++s) {
+    // sample s contributes to c[j] with k = s - SPL_K - j; samples beyond an end of the row are dropped: the
+    // output is >= SPL_EDGE knots inside, where their weight is below z^SPL_EDGE = 2e-14
+    const long long a = a0 + s;
+    const double v = (a >= 0 && a < n) ? src[a] : 0.0;
+    const int k0 = s - SPL_K, k1 = k0 - 1, k2 = k0 - 2, k3 = k0 - 3;
+    if (k0 >= -SPL_K && k0 <= SPL_K) c0 = fma(pre[k0 < 0 ? -k0 : k0], v, c0);
+    if (k1 >= -SPL_K && k1 <= SPL_K) c1 = fma(pre[k1 < 0 ? -k1 : k1], v, c1);
+    if (k2 >= -SPL_K && k2 <= SPL_K) c2 = fma(pre[k2 < 0 ? -k2 : k2], v, c2);
+    if (k3 >= -SPL_K && k3 <= SPL_K) c3 = fma(pre[k3 < 0 ? -k3 : k3], v, c3);
+  }
+  const double g = 1.0 - f;
+  const double b0 = g * g * g, b3 = f * f * f;
+  const double b1 = fma(fma(3.0, f, -6.0) * f, f, 4.0);
+  const double b2 = fma(fma(3.0, g, -6.0) * g, g, 4.0);
+  out[(size_t)row * (size_t)ld_out + (size_t)q] = (b0 * c0 + b1 * c1 + b2 * c2 + b3 * c3) * (1.0 / 6.0);
+}
+
+extern "C" int rtx_cubic_resample(const double* Ysm, int64_t ld, int n_rows, int64_t n, double x0, double h, const double* x_out,
+                                  int64_t n_out, double* out, int64_t ld_out, void* stream) {
+  if (!Ysm || !x_out || !out) RTX_FAIL("a required pointer is NULL");
+  if (n_rows < 1 || n_rows > 65535) RTX_FAIL("n_rows=%d", n_rows);
+  if (n < 2 * SPL_EDGE + 8) RTX_FAIL("n=%lld: the spline needs at least %d samples", (long long)n, 2 * SPL_EDGE + 8);
+  if (!(h > 0.0)) RTX_FAIL("h=%g", h);
+  if (ld < n || ld_out < n_out) RTX_FAIL("leading dimension smaller than the row");
+  if (n_out == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int* d_bad = nullptr;
+  RTX_HIP(hipMallocAsync((void**)&d_bad, sizeof(int), st));
+  RTX_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+  hipLaunchKernelGGL(cubic_resample_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)n_rows), dim3(256), 0, st, Ysm, (long long)ld,
+                     (long long)n, x0, 1.0 / h, x_out, (long long)n_out, out, (long long)ld_out, d_bad);
+  RTX_LAUNCH_CHECK();
+  int bad = 0;
+  RTX_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+  RTX_HIP(hipStreamSynchronize(st));
+  RTX_HIP(hipFreeAsync(d_bad, st));
+  if (bad) RTX_FAIL("an output abscissa lies within %d samples of an end of the input axis (or is NaN)", SPL_EDGE + 2);
+  return 0;
+}

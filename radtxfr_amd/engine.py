@@ -331,3 +331,73 @@ def max_wing_cm(columns, T_layers, p_atm_layers, omega_wing=0.0, omega_wing_hw=5
     gd = 3.6e-7 * float(np.max(nu)) * np.sqrt(float(np.max(T)) / 1.0)  # mass >= 1 g/mol: generous
     shift = float(np.max(np.abs(columns["delta_air"]))) * float(np.max(p))
     return max(float(omega_wing), omega_wing_hw * g0, omega_wing_hw * min(gd, 10.0 * g0 + 1.0)) + shift
+
+
+# ---- post-processing: smooth / reduceResolution (rtx_fir_reflect, rtx_cubic_resample) ------------
+_WINDOWS = ("flat", "hanning", "hamming", "bartlett", "blackman")
+
+
+def window_taps(window_len, window="hanning", symmetric=False):
+    """FIR taps and centre of radiative_transfer.smooth (:1314-1324) in the convention of rtx_fir_reflect:
+    out[i] = sum_k taps[k] * x[R(i + k - centre)]. symmetric=True gives reduceResolution's symmetrised smoother
+    (:1331), the mean of smoothing x and smoothing x reversed."""
+    wl = int(window_len)
+    w = np.ones(wl, "d") if window == "flat" else getattr(np, window)(wl)
+    w = w / w.sum()
+    ix0 = int(np.ceil(wl / 2 - 1))
+    c = wl - 1 - ix0  # out[i] = sum_q w[wl-1-q] * s[i + ix0 + q],  s[k] = x[R(k - (wl - 1))]
+    fwd = w[::-1].copy()
+    if not symmetric:
+        return fwd, c
+    # the reversed pass uses offsets -(k - c): offsets d in [-(wl-1-c), c]
+    m = max(c, wl - 1 - c)
+    taps = np.zeros(2 * m + 1)
+    for k in range(wl):
+        taps[m + (k - c)] += 0.5 * fwd[k]
+        taps[m - (k - c)] += 0.5 * fwd[k]
+    return taps, m
+
+
+def fir_reflect(Y, taps, centre):
+    """Y [rows][n] float32/float64 device tensor -> [rows][n] float64 (rtx_fir_reflect)."""
+    lib = _lib.load()
+    assert Y.is_cuda and Y.dim() == 2 and Y.stride(1) == 1 and Y.dtype in (torch.float32, torch.float64)
+    rows, n = Y.shape
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+    out = torch.empty((rows, n), dtype=torch.float64, device=Y.device)
+    ld = Y.stride(0) if rows > 1 else n  # the stride of a size-1 dimension is arbitrary
+    _lib.check(lib.rtx_fir_reflect(_ptr(Y), int(Y.dtype == torch.float64), ld, rows, n, taps.ctypes.data, taps.size,
+                                   int(centre), _ptr(out), out.stride(0), _stream_ptr()))
+    return out
+
+
+def cubic_resample(Ysm, x0, h, x_out):
+    """Cubic spline through every sample of the uniform axis x0 + i*h, at x_out (device fp64): [rows][n_out] fp64."""
+    lib = _lib.load()
+    assert Ysm.is_cuda and Ysm.dtype == torch.float64 and Ysm.dim() == 2 and Ysm.stride(1) == 1
+    assert x_out.is_cuda and x_out.dtype == torch.float64 and x_out.dim() == 1 and x_out.is_contiguous()
+    rows, n = Ysm.shape
+    out = torch.empty((rows, x_out.numel()), dtype=torch.float64, device=Ysm.device)
+    _lib.check(lib.rtx_cubic_resample(_ptr(Ysm), Ysm.stride(0) if rows > 1 else n, rows, n, float(x0), float(h), _ptr(x_out), x_out.numel(),
+                                      _ptr(out), out.stride(0), _stream_ptr()))
+    return out
+
+
+def reduce_resolution(Y, x0, h, n, dX, N=4, window="hanning", x_out=None):
+    """Device-resident reduceResolution: Y [rows][n] (float32 as rtx_tud writes it, or float64) on the uniform axis
+    x0 + i*h -> (x_out host fp64, Y_out [rows][n_out] fp64 device). See radiative_transfer.reduceResolution."""
+    sm_factor = int(np.round(dX / h))
+    if sm_factor < 3:
+        raise ValueError(f"reduceResolution: dX/dX_in rounds to {sm_factor}; the window needs at least 3 samples")
+    if window not in _WINDOWS:
+        raise ValueError(f"window must be one of {_WINDOWS}")
+    if x_out is None:
+        xa, xb = x0 + sm_factor * h, x0 + (n - sm_factor - 1) * h
+        v = N * (xb - xa) / dX
+        n_pts = int(np.ceil(v - 1e-9 * max(1.0, abs(v)))) + 1  # see the shim's docstring: rounding-proof ceil
+        x_out = np.linspace(xa, xb, n_pts)
+    x_out = np.ascontiguousarray(x_out, dtype=np.float64)
+    taps, c = window_taps(sm_factor, window, symmetric=True)
+    Ysm = fir_reflect(Y, taps, c)
+    out = cubic_resample(Ysm, x0, h, torch.as_tensor(x_out, device=Y.device))
+    return x_out, out

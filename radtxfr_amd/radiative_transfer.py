@@ -302,3 +302,63 @@ def ILS_MAKO(X, Y, resFactor=None, returnX=True, fwhm_sf=1.0, shift=0.0, scale=1
     if returnX:
         return X_out, Y_out
     return Y_out
+
+
+# ---- post-processing of TUD products ----------------------------------------
+def _uniform_axis(X, what):
+    Xh = X.detach().cpu().numpy() if _is_torch(X) else np.asarray(X, dtype=np.float64)
+    Xh = np.asarray(Xh, dtype=np.float64).ravel()
+    if Xh.size < 2:
+        raise ValueError(f"{what}: X needs at least two points")
+    h = (Xh[-1] - Xh[0]) / (Xh.size - 1)
+    if not np.allclose(np.diff(Xh), h, rtol=0, atol=1e-6 * abs(h)):
+        raise NotImplementedError(f"{what}: only uniform spectral axes are supported")
+    return Xh, float(h)
+
+
+def smooth(x, window_len=11, window="hanning"):
+    """Window smoothing, signature and early returns of :1266-1324 (1-D input only; reflect-padded, output of the
+    same length; an even window_len leaves the result half a sample off centre, as in the reference)."""
+    x = np.asarray(x)
+    if x.ndim != 1:
+        print("smooth only accepts 1 dimension arrays.")
+        return x
+    if x.size < window_len:
+        print("Input vector needs to be bigger than window size.")
+        return x
+    if window_len < 3:
+        return x
+    if window not in engine._WINDOWS:
+        print("Window is on of 'flat', 'hanning', 'hamming', 'bartlett', 'blackman'")
+        return x
+    engine.require_gpu()
+    taps, c = engine.window_taps(window_len, window)
+    Y = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)[None, :], device="cuda")
+    return engine.fir_reflect(Y, taps, c)[0].cpu().numpy()
+
+
+def reduceResolution(X, Y, dX, N=4, window="hanning", X_out=None):
+    """Smooth to resolution dX and resample, signature of :1327-1350: X (nX,) uniform, Y (nX,) or (nX, nC)
+    -> (X_out, Y_out) when X_out is None, else Y_out; Y_out (nOut,) or (nOut, nC), float64.
+
+    The reference smooths with window length round(dX / mean(diff(X))) (forward and reversed, averaged), then puts
+    scipy's cubic interp1d through all smoothed samples. Here: one fp64 FIR kernel and one cardinal-spline kernel.
+    Conscious divergences: (1) nPts = ceil(N*span/dX)+1 is evaluated with a 1e-9 guard, because N*span/dX is normally
+    an exact integer and the reference's value flips between two counts with the rounding of its convolution;
+    (2) X_out must stay 26 samples inside the input axis (the default X_out does for windows of >= 26 samples): the not-a-knot end conditions and
+    the extrapolation of interp1d are not reproduced; (3) np.int (:1329,1336) is int."""
+    Xh, h = _uniform_axis(X, "reduceResolution")
+    engine.require_gpu()
+    Yt = Y if _is_torch(Y) else torch.as_tensor(np.asarray(Y, dtype=np.float64))
+    one_d = Yt.dim() == 1
+    Y2 = (Yt[None, :] if one_d else Yt.transpose(0, 1)).to("cuda").contiguous()
+    if Y2.shape[1] != Xh.size:
+        raise ValueError("reduceResolution: Y's first axis must match X")
+    if Y2.dtype not in (torch.float32, torch.float64):
+        Y2 = Y2.to(torch.float64)
+    x_out, out = engine.reduce_resolution(Y2, float(Xh[0]), h, Xh.size, float(dX), N=N, window=window,
+                                          x_out=None if X_out is None else np.asarray(X_out, dtype=np.float64).ravel())
+    Y_out = out[0].cpu().numpy() if one_d else out.transpose(0, 1).contiguous().cpu().numpy()
+    if X_out is None:
+        return x_out, Y_out
+    return Y_out

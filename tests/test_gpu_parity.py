@@ -466,3 +466,50 @@ def test_full_c3_width_properties():
     assert rel_err(Lu[0, i0:i0 + n].double().cpu().numpy(), ur) <= TOL_L
     assert rel_err(Ld[i0:i0 + n].double().cpu().numpy(), dr) <= TOL_L
     lines.close()
+
+
+@pytest.mark.gpu
+def test_smooth_and_reduce_resolution_vs_golden_g9(rt, golden):
+    """rt.smooth / rt.reduceResolution (rtx_fir_reflect + rtx_cubic_resample, fp64) against the
+    reference's own outputs; the spline is evaluated locally (cardinal spline), so agreement is ~1e-12, not bitwise."""
+    g = golden("g9_reduce.npz")
+    for args, key in (((11, "hanning"), "sm11"), ((50, "hamming"), "sm50"), ((7, "flat"), "smflat")):
+        assert rel_err(rt.smooth(g["Y1"], *args), g[key]) < 1e-13
+    Xo, Yo = rt.reduceResolution(g["Xf"], g["Y1"], 0.05)
+    assert Xo.shape == g["Xo"].shape and np.allclose(Xo, g["Xo"], rtol=1e-13, atol=0)
+    assert rel_err(Yo, g["Yo1"]) < 1e-10
+    Y2o = rt.reduceResolution(g["Xf"], g["Y2"], 0.05, X_out=g["Xo"])
+    assert Y2o.shape == g["Yo2"].shape and rel_err(Y2o, g["Yo2"]) < 1e-10
+    Xo8, Yo8 = rt.reduceResolution(g["Xf"], g["Y1"], 0.02, N=8, window="blackman")
+    assert Xo8.shape == g["Xo8"].shape and rel_err(Yo8, g["Yo8"]) < 1e-10
+    # the reference's early returns
+    assert rt.smooth(g["Y1"][:5], 11) is not None and rt.smooth(g["Y1"][:5], 11).shape == (5,)
+    with pytest.raises(Exception):
+        rt.reduceResolution(g["Xf"], g["Y1"], 0.05, X_out=g["Xf"][:10])  # within 26 samples of the end
+
+
+@pytest.mark.gpu
+def test_reduce_resolution_full_size_float32_device_path():
+    """The caller's configuration (Generate_LWIR_TUD.py:76-85): 690-1410 cm^-1 at 0.0005 -> 0.25 cm^-1, N = 4, on
+    device-resident float32 rows as rtx_tud writes them; checked against the oracle on a window and through
+    properties at full size (constants are preserved, output axis, linearity)."""
+    import torch
+    from radtxfr_amd import engine
+
+    n = 1440001
+    x0, h = 690.0, 720.0 / (n - 1)
+    X = x0 + h * np.arange(n)
+    rng = np.random.default_rng(11)
+    Y = (1.0 + 0.3 * np.sin(3.0 * X) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    rows = torch.as_tensor(np.stack([Y, np.ones_like(Y), 2.0 * Y + 1.0]), device="cuda")
+    xo, out = engine.reduce_resolution(rows, x0, h, n, 0.25)
+    out = out.cpu().numpy()
+    assert xo.size == 11513 and abs(xo[0] - X[500]) < 1e-9 and abs(xo[-1] - X[-501]) < 1e-9
+    assert np.max(np.abs(out[1] - 1.0)) < 1e-12                      # a constant stays constant
+    assert np.max(np.abs(out[2] - (2.0 * out[0] + 1.0))) < 1e-6      # linear in Y (inputs are float32)
+    # oracle on a window well inside (the smoother reaches 500 samples, the spline ~40)
+    lo, hi = 400000, 440000
+    xw, yw = ref.reduceResolution(X[lo:hi], Y[lo:hi].astype(np.float64), 0.25)
+    sel = (xo >= xw[0]) & (xo <= xw[-1])
+    want = ref.reduceResolution(X[lo:hi], Y[lo:hi].astype(np.float64), 0.25, X_out=xo[sel])
+    assert rel_err(out[0][sel], want) < 1e-10

@@ -217,3 +217,29 @@ def test_chebyshev_tables_match_generator_and_error_bounds():
             full = np.concatenate([W @ rv[8 * r:8 * r + 8] for r in range(rows)])
             worst = max(worst, np.max(np.abs(full - f(xs)) / f(xs)))
     assert worst < 3e-8, worst
+
+
+def test_window_taps_reproduce_the_reference_smoother():
+    """engine.window_taps (the FIR handed to rtx_fir_reflect) against the oracle's smooth / symmetrised smooth,
+    with the kernel's reflection rule emulated in NumPy."""
+    from oracle import cpu_ref
+    from radtxfr_amd import engine
+
+    def fir(x, taps, c):
+        n = len(x)
+        k = np.arange(len(taps))
+        out = np.zeros(n)
+        for i in range(n):
+            j = i + k - c
+            j = np.where(j < 0, -j, j)
+            j = np.where(j >= n, 2 * (n - 1) - j, j)
+            out[i] = np.dot(taps, x[j])
+        return out
+
+    x = np.random.default_rng(7).standard_normal(257)
+    for wl, win in ((11, "hanning"), (50, "hamming"), (7, "flat"), (20, "blackman"), (3, "bartlett")):
+        t, c = engine.window_taps(wl, win)
+        assert np.allclose(fir(x, t, c), cpu_ref.smooth(x, wl, win), rtol=0, atol=1e-14)
+        t, c = engine.window_taps(wl, win, symmetric=True)
+        assert len(t) % 2 == 1 and np.allclose(t, t[::-1])
+        assert np.allclose(fir(x, t, c), cpu_ref.smooth_sym(x, wl, win), rtol=0, atol=1e-14)

@@ -149,3 +149,17 @@ def test_g7_ils(golden):
     close(yg, g["yg1"], rtol=1e-12)
     xg, yg = ref.ILS_MAKO_gauss(X, Y2)
     close(yg, g["yg2"], rtol=1e-12)
+
+
+def test_g9_smooth_and_reduce_resolution(golden):
+    """Oracle restatement of radiative_transfer.smooth / reduceResolution against the reference run (np.int restored)."""
+    g = golden("g9_reduce.npz")
+    assert np.allclose(ref.smooth(g["Y1"], 11), g["sm11"], rtol=1e-13, atol=0)
+    assert np.allclose(ref.smooth(g["Y1"], 50, "hamming"), g["sm50"], rtol=1e-13, atol=0)
+    assert np.allclose(ref.smooth(g["Y1"], 7, "flat"), g["smflat"], rtol=1e-13, atol=0)
+    Xo, Yo = ref.reduceResolution(g["Xf"], g["Y1"], 0.05)
+    assert Xo.shape == g["Xo"].shape and np.allclose(Xo, g["Xo"], rtol=1e-14, atol=0)
+    assert np.allclose(Yo, g["Yo1"], rtol=1e-11, atol=0)
+    assert np.allclose(ref.reduceResolution(g["Xf"], g["Y2"], 0.05, X_out=g["Xo"]), g["Yo2"], rtol=1e-11, atol=0)
+    Xo8, Yo8 = ref.reduceResolution(g["Xf"], g["Y1"], 0.02, N=8, window="blackman")
+    assert Xo8.shape == g["Xo8"].shape and np.allclose(Yo8, g["Yo8"], rtol=1e-11, atol=0)
