@@ -91,6 +91,21 @@ int rtx_line_prep(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, 
                   const double* weight_h, const double* mass_h, double dil_air, double dil_self,
                   double omega_wing, double omega_wing_hw, double intensity_threshold,
                   double scale, void* stream);
+/* The same prologue for the other hapi profiles that share it; rtx_voigt_sum then sums whatever
+ * profile the records describe. rtx_line_prep == profile RTX_PROFILE_VOIGT.
+ *   RTX_PROFILE_LORENTZ  absorptionCoefficient_Lorentz, misc/hapi.py:11144-11375: PROFILE_LORENTZ (:10150),
+ *                        OmegaWingF = max(OmegaWing, OmegaWingHW*Gamma0) (:11364)
+ *   RTX_PROFILE_DOPPLER  absorptionCoefficient_Doppler, misc/hapi.py:11384-11559: PROFILE_DOPPLER (:10160), its own
+ *                        GammaD constants (:11534-11538), OmegaWingF = max(OmegaWing, OmegaWingHW*GammaD) (:11540),
+ *                        Shift0 = dil_air * delta_air * p (:11543; pass dil_air = 0 for LineShift=False) */
+#define RTX_PROFILE_VOIGT 0
+#define RTX_PROFILE_LORENTZ 1
+#define RTX_PROFILE_DOPPLER 2
+int rtx_line_prep_profile(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, int n_layers,
+                          const double* T_h, const double* p_atm_h, const double* qratio_h,
+                          const double* weight_h, const double* mass_h, double dil_air,
+                          double dil_self, double omega_wing, double omega_wing_hw,
+                          double intensity_threshold, double scale, int profile, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Voigt line-sum. Replaces the per-line PROFILE_VOIGT + scatter-add loop, misc/hapi.py:11050,

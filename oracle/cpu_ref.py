@@ -422,9 +422,30 @@ def line_params(tbl, T, p, Diluent=None, GammaL="gamma_air"):
     return {"S": S, "GammaD": GammaD, "Gamma0": Gamma0, "Shift0": Shift0, "M": M, "I": I}
 
 
+def PROFILE_LORENTZ(sg0, Gam0, sg):
+    """misc/hapi.py:10142-10150."""
+    return Gam0 / (np.pi * (Gam0 ** 2 + (sg - sg0) ** 2))
+
+
+def PROFILE_DOPPLER(sg0, GamD, sg):
+    """misc/hapi.py:10152-10160 (cSqrtLn2divSqrtPi = sqrt(ln2/pi), cLn2 = ln2)."""
+    return 0.469718639319144059835 * np.exp(-0.6931471805599 * ((sg - sg0) / GamD) ** 2) / GamD
+
+
+def absorptionCoefficient_Lorentz(tbl, **kw):
+    """misc/hapi.py:11144-11375: the Voigt loop with PROFILE_LORENTZ and OmegaWingF = max(OmegaWing, HW*Gamma0)."""
+    return absorptionCoefficient_Voigt(tbl, _profile="lorentz", **kw)
+
+
+def absorptionCoefficient_Doppler(tbl, LineShift=True, **kw):
+    """misc/hapi.py:11384-11559: PROFILE_DOPPLER, GammaD from the function's own SI constants (:11534-11538),
+    OmegaWingF = max(OmegaWing, HW*GammaD), Shift0 = delta_air*p/pref when LineShift (:11510-11513, 11543)."""
+    return absorptionCoefficient_Voigt(tbl, _profile="doppler", _lineshift=LineShift, **kw)
+
+
 def absorptionCoefficient_Voigt(tbl, Components=None, T=296.0, p=1.0, OmegaGrid=None, OmegaWing=0.0,
                                 OmegaWingHW=50.0, HITRAN_units=True, GammaL="gamma_air", Diluent=None,
-                                IntensityThreshold=0.0):
+                                IntensityThreshold=0.0, _profile="voigt", _lineshift=True):
     """misc/hapi.py:10906-11141 on an explicit grid. `tbl` is the column dict of the line table
     (LOCAL_TABLE_CACHE[name]['data'], :438-463). Components: list of (M,I[,abundance]); None = every
     (M,I) in the table at natural abundance (:10237-10251). Returns (Omegas, Xsect)."""
@@ -455,12 +476,25 @@ def absorptionCoefficient_Voigt(tbl, Components=None, T=296.0, p=1.0, OmegaGrid=
         if S < IntensityThreshold:
             continue
         GammaD, Gamma0, Shift0 = P["GammaD"][r], P["Gamma0"][r], P["Shift0"][r]
-        W = max(OmegaWing, OmegaWingHW * Gamma0, OmegaWingHW * GammaD)
+        if _profile == "doppler":
+            mass = t["mass"][(int(P["M"][r]), int(P["I"][r]))]
+            GammaD = (1.1774100225 / 2.99792458e8) * np.sqrt(1.3806503e-23 / 1.66053873e-27) * np.sqrt(T) * nu[r] / np.sqrt(mass)
+            Shift0 = (float(sub["delta_air"][r]) if _lineshift else 0.0) * p / PREF
+            W = max(OmegaWing, OmegaWingHW * GammaD)
+        elif _profile == "lorentz":
+            W = max(OmegaWing, OmegaWingHW * Gamma0)
+        else:
+            W = max(OmegaWing, OmegaWingHW * Gamma0, OmegaWingHW * GammaD)
         lo = _bisect.bisect(glist, nu[r] - W)
         hi = _bisect.bisect(glist, nu[r] + W)
         if hi <= lo:
             continue
-        ls = PROFILE_VOIGT(nu[r] + Shift0, GammaD, Gamma0, Omegas[lo:hi])[0]
+        if _profile == "doppler":
+            ls = PROFILE_DOPPLER(nu[r] + Shift0, GammaD, Omegas[lo:hi])
+        elif _profile == "lorentz":
+            ls = PROFILE_LORENTZ(nu[r] + Shift0, Gamma0, Omegas[lo:hi])
+        else:
+            ls = PROFILE_VOIGT(nu[r] + Shift0, GammaD, Gamma0, Omegas[lo:hi])[0]
         mi = (int(P["M"][r]), int(P["I"][r]))
         Xsect[lo:hi] += factor / NAT[mi] * ABUN[mi] * S * ls
     return Omegas, Xsect

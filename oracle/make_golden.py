@@ -58,6 +58,30 @@ def make_g9(rt):
     save("g9_reduce.npz", Xf=Xf, Y1=Y1, Y2=Y2, sm11=sm11, sm50=sm50, smflat=smflat, Xo=Xo, Yo1=Yo1, Yo2=Yo2, Xo8=Xo8, Yo8=Yo8)
 
 
+def make_g10(hapi):
+    """G10: absorptionCoefficient_Lorentz / _Doppler on the G4 table."""
+    atm = synthetic.load_standard_atmosphere()
+    tbl = synthetic.synth_line_table(synthetic.SEED_C2, 2000, 675.0, 1425.0)
+    inject_table(hapi, "g10", tbl)
+    out = {}
+    gl = np.linspace(900.0, 960.0, 30001)  # 0.002 cm^-1
+    for tag, row in (("l01", 0), ("l32", 31)):
+        Tk, pk = float(atm[row, 5]), float(atm[row, 4]) / 101325.0
+        _, xs_ = quiet(hapi.absorptionCoefficient_Lorentz, SourceTables="g10", Environment={"T": Tk, "p": pk}, OmegaGrid=gl)
+        out["T_" + tag], out["p_" + tag], out["lor_" + tag] = Tk, pk, xs_
+    _, out["lor_opt"] = quiet(hapi.absorptionCoefficient_Lorentz, Components=[(1, 1), (2, 1, 0.5)], SourceTables="g10",
+                              Environment={"T": 250.0, "p": 0.4}, OmegaGrid=gl[5000:12000], HITRAN_units=False,
+                              OmegaWing=1.0, OmegaWingHW=20.0, Diluent={"air": 0.7, "self": 0.3})
+    gd = np.linspace(1000.0, 1003.0, 30001)  # 0.0001 cm^-1: Doppler HWHM here is ~1e-3
+    for tag, (Tk, pk) in (("a", (296.0, 1.0)), ("b", (220.0, 0.05))):
+        _, out["dop_" + tag] = quiet(hapi.absorptionCoefficient_Doppler, SourceTables="g10", Environment={"T": Tk, "p": pk},
+                                     OmegaGrid=gd)
+    _, out["dop_noshift"] = quiet(hapi.absorptionCoefficient_Doppler, SourceTables="g10", Environment={"T": 296.0, "p": 1.0},
+                                  OmegaGrid=gd, LineShift=False, HITRAN_units=False, OmegaWing=0.05)
+    save("g10_lorentz_doppler.npz", seed=synthetic.SEED_C2, n_lines=2000, nu_lo=675.0, nu_hi=1425.0, gl_lo=900.0, gl_hi=960.0,
+         gl_n=30001, gd_lo=1000.0, gd_hi=1003.0, gd_n=30001, **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rt, hapi, ils_gauss = load()
@@ -206,11 +230,15 @@ def main():
          yo2=yo2, xo3=xo3, yo3=yo3, yo4=yo4, xg1=xg1, yg1=yg1, xg2=xg2, yg2=yg2)
 
     make_g9(rt)
+    make_g10(hapi)
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["g9"]:  # regenerate only the newest fixture
+    if sys.argv[1:] == ["g9"]:  # regenerate only one of the newer fixtures
         os.makedirs(OUT, exist_ok=True)
         make_g9(load()[0])
+    elif sys.argv[1:] == ["g10"]:
+        os.makedirs(OUT, exist_ok=True)
+        make_g10(load()[1])
     else:
         main()

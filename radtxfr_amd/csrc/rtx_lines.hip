@@ -169,6 +169,7 @@ struct PrepArgs {
   int n_layers, n_species;
   const double *T, *p, *qratio, *weight, *mass;  // device copies of the small per-layer tables
   double dil_air, dil_self, omega_wing, omega_wing_hw, thresh, scale;
+  int profile;  // RTX_PROFILE_VOIGT / _LORENTZ / _DOPPLER
   GridDev g;
   LineRec* rec;
   LineRec64* rec64;
@@ -222,7 +223,9 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     const double S = a.sw[l] * a.qratio[(size_t)sp * a.n_layers + k] * ch / zn;
     // GammaD, misc/hapi.py:11085-11087
     const double m = a.mass[sp] * H_CMASSMOL * 1000.0;
-    const double GammaD = sqrt(2.0 * H_CBOLTS * T * log(2.0) / m / (H_CC * H_CC)) * nu;
+    double GammaD = sqrt(2.0 * H_CBOLTS * T * log(2.0) / m / (H_CC * H_CC)) * nu;
+    if (a.profile == RTX_PROFILE_DOPPLER)  // absorptionCoefficient_Doppler's own SI constants, misc/hapi.py:11534-11538
+      GammaD = (1.1774100225 / 2.99792458e8) * sqrt(1.3806503e-23 / 1.66053873e-27) * sqrt(T) * nu / sqrt(a.mass[sp]);
     // Gamma0 / Shift0 over the diluent mix, misc/hapi.py:11090-11128
     double Gamma0 = 0.0, Shift0 = 0.0;
     const double tr = H_TREF / T;
@@ -238,18 +241,30 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       const double ds = a.delta_self ? a.delta_self[l] : 0.0;
       Shift0 += a.dil_self * ((ds + 0.0 * (T - H_TREF)) * p / 1.0);
     }
-    // OmegaWingF and the window, misc/hapi.py:11131-11134
-    const double W = fmax(a.omega_wing, fmax(a.omega_wing_hw * Gamma0, a.omega_wing_hw * GammaD));
+    if (a.profile == RTX_PROFILE_DOPPLER) {  // no pressure broadening; Shift0 = delta_air * p (misc/hapi.py:11543), set by the host through dil_air = 1 / 0 (LineShift)
+      Gamma0 = 0.0;
+      Shift0 = a.dil_air * a.delta_air[l] * p;
+    }
+    // OmegaWingF and the window: Voigt misc/hapi.py:11131-11134, Lorentz :11364, Doppler :11540
+    const double W = a.profile == RTX_PROFILE_LORENTZ   ? fmax(a.omega_wing, a.omega_wing_hw * Gamma0)
+                     : a.profile == RTX_PROFILE_DOPPLER ? fmax(a.omega_wing, a.omega_wing_hw * GammaD)
+                                                        : fmax(a.omega_wing, fmax(a.omega_wing_hw * Gamma0, a.omega_wing_hw * GammaD));
     long long glo = grid_bisect_right(g, nu - W);
     long long ghi = grid_bisect_right(g, nu + W);
     int lo = clamp_local(glo, g), hi = clamp_local(ghi, g);
-    const bool dropped = !(w != 0.0) || (S < a.thresh) || !(GammaD > 0.0);
+    const bool dropped = !(w != 0.0) || (S < a.thresh) || !(GammaD > 0.0) || (a.profile == RTX_PROFILE_LORENTZ && !(Gamma0 > 0.0));
     if (dropped || hi <= lo) { lo = 0; hi = 0; }
     // profile parameters: pcqsdhc PART1, misc/hapi.py:9900-9915
     const double sg0 = nu + Shift0;
-    const double cte = sqrt(log(2.0)) / GammaD;
-    const double y = Gamma0 * cte;
-    const double A = dropped ? 0.0 : w * S * cte / sqrt(M_PI) * a.scale;
+    // Lorentz (PROFILE_LORENTZ, misc/hapi.py:10150): with x = (nu - sg0)/Gamma0 the profile is (1/(pi Gamma0)) / (x^2 + 1)
+    // = (x^2 K + K) / ((x^2 + 2) x^2 + 1), i.e. the line-sum's far-wing rational with b1 = 2, b0 = 1, Ay = Ay0 = K:
+    // the same kernels evaluate it everywhere (no band: y is set to 15), poles at |nu - sg0| = Gamma0 as for Voigt.
+    // Doppler (PROFILE_DOPPLER, :10160) is the Voigt profile at y = 0: Re w(x) = exp(-x^2); the band |x| < 15 goes
+    // through the fp64 Weideman pass, beyond it the reference's exp(-225) = 1e-98 is dropped.
+    const bool lor = a.profile == RTX_PROFILE_LORENTZ;
+    const double cte = lor ? 1.0 / Gamma0 : sqrt(log(2.0)) / GammaD;
+    const double y = lor ? 15.0 : Gamma0 * cte;
+    const double A = dropped ? 0.0 : (lor ? w * S * cte / M_PI * a.scale : w * S * cte / sqrt(M_PI) * a.scale);
     // nearest grid index to the shifted centre (global), then the residual in fp64
     long long gi0 = llrint((sg0 - g.xmin) / g.step);
     const long long M = 1000000000LL;
@@ -261,10 +276,10 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     r.a = (float)ax;
     r.c = (float)frac_x;
     const double yh = y * y + 0.5;
-    r.b1 = (float)(2.0 * (y * y) - 1.0);
-    r.b0 = (float)(yh * yh);
-    r.Ay = (float)(A * y * 0.56418958354775628);
-    r.Ay0 = (float)(A * y * 0.56418958354775628 * yh);
+    r.b1 = lor ? 2.0f : (float)(2.0 * (y * y) - 1.0);
+    r.b0 = lor ? 1.0f : (float)(yh * yh);
+    r.Ay = lor ? (float)A : (float)(A * y * 0.56418958354775628);
+    r.Ay0 = lor ? (float)A : (float)(A * y * 0.56418958354775628 * yh);
     r.y = (float)y;
     r.A = (float)A;
     r.i0 = sat_local(gi0 - g.offset, g.n);
@@ -306,11 +321,12 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
   }
 }
 
-extern "C" int rtx_line_prep(rtx_prep* P, const rtx_lines* L, const rtx_grid* grid, int n_layers, const double* T_h,
+extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_grid* grid, int n_layers, const double* T_h,
                              const double* p_atm_h, const double* qratio_h, const double* weight_h, const double* mass_h,
                              double dil_air, double dil_self, double omega_wing, double omega_wing_hw,
-                             double intensity_threshold, double scale, void* stream) {
+                             double intensity_threshold, double scale, int profile, void* stream) {
   if (!P || !L) RTX_FAIL("prep/lines is NULL");
+  if (profile < RTX_PROFILE_VOIGT || profile > RTX_PROFILE_DOPPLER) RTX_FAIL("profile=%d", profile);
   if (rtx_check_grid(grid)) return 1;
   if (P->n_lines != L->n) RTX_FAIL("prep object was created for %lld lines, table has %lld", P->n_lines, L->n);
   if (n_layers < 1 || n_layers > P->max_layers) RTX_FAIL("n_layers=%d outside [1,%d]", n_layers, P->max_layers);
@@ -341,11 +357,19 @@ extern "C" int rtx_line_prep(rtx_prep* P, const rtx_lines* L, const rtx_grid* gr
   a.n_lines = L->n; a.n_layers = n_layers; a.n_species = ns;
   a.T = d; a.p = d + nT; a.qratio = d + 2 * nT; a.weight = d + 2 * nT + nQ; a.mass = d + 2 * nT + 2 * nQ;
   a.dil_air = dil_air; a.dil_self = dil_self; a.omega_wing = omega_wing; a.omega_wing_hw = omega_wing_hw;
-  a.thresh = intensity_threshold; a.scale = scale;
+  a.thresh = intensity_threshold; a.scale = scale; a.profile = profile;
   a.g = to_dev(grid);
   a.rec = P->rec; a.rec64 = P->rec64; a.ic = P->ic; a.maxhw = P->maxhw; a.smally = P->smally;
   dim3 grd((unsigned)((L->n + 255) / 256), (unsigned)n_layers);
   hipLaunchKernelGGL(line_prep_kernel, grd, dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int rtx_line_prep(rtx_prep* P, const rtx_lines* L, const rtx_grid* grid, int n_layers, const double* T_h,
+                             const double* p_atm_h, const double* qratio_h, const double* weight_h, const double* mass_h,
+                             double dil_air, double dil_self, double omega_wing, double omega_wing_hw,
+                             double intensity_threshold, double scale, void* stream) {
+  return rtx_line_prep_profile(P, L, grid, n_layers, T_h, p_atm_h, qratio_h, weight_h, mass_h, dil_air, dil_self, omega_wing,
+                               omega_wing_hw, intensity_threshold, scale, RTX_PROFILE_VOIGT, stream);
 }

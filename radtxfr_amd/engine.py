@@ -191,8 +191,10 @@ def species_factors(species, T_layers, partitionFunction=None):
 
 
 def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air=1.0, dil_self=0.0, omega_wing=0.0,
-              omega_wing_hw=50.0, intensity_threshold=0.0, scale=1.0, partitionFunction=None, qratio=None, mass=None):
-    """Prologue + line-sum for n_layers homogeneous states on `grid` (rtx_line_prep + rtx_voigt_sum).
+              omega_wing_hw=50.0, intensity_threshold=0.0, scale=1.0, partitionFunction=None, qratio=None, mass=None,
+              profile=0):
+    """Prologue + line-sum for n_layers homogeneous states on `grid` (rtx_line_prep_profile + rtx_voigt_sum);
+    profile 0 Voigt, 1 Lorentz, 2 Doppler (include/radtxfr_hip.h).
     weight[nS][nL] multiplies S(T) per species and layer. Outputs are [nL][grid.n] device tensors."""
     lib = _lib.load()
     T = np.atleast_1d(np.asarray(T, dtype=np.float64))
@@ -207,9 +209,9 @@ def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air
     w_h, w_p = _h(np.broadcast_to(weight, (len(lines.species), nL)))
     m_h, m_p = _h(mass)
     st = _stream_ptr()
-    _lib.check(lib.rtx_line_prep(plan._h, lines._h, grid.byref(), nL, T_p, p_p, q_p, w_p, m_p, float(dil_air),
-                                 float(dil_self), float(omega_wing), float(omega_wing_hw), float(intensity_threshold),
-                                 float(scale), st))
+    _lib.check(lib.rtx_line_prep_profile(plan._h, lines._h, grid.byref(), nL, T_p, p_p, q_p, w_p, m_p, float(dil_air),
+                                         float(dil_self), float(omega_wing), float(omega_wing_hw),
+                                         float(intensity_threshold), float(scale), int(profile), st))
     ld = grid.n
     for o, dt in ((out_f32, torch.float32), (out_f64, torch.float64)):
         if o is not None:

@@ -94,19 +94,12 @@ def arange_(lower, upper, step):
     return np.linspace(lower, upper_new, int(npnt))
 
 
-def absorptionCoefficient_Voigt(Components=None, SourceTables=None, partitionFunction=PYTIPS, Environment=None,
-                                OmegaRange=None, OmegaStep=None, OmegaWing=None,
-                                IntensityThreshold=DefaultIntensityThreshold, OmegaWingHW=DefaultOmegaWingHW,
-                                GammaL="gamma_air", HITRAN_units=True, LineShift=True, File=None, Format=None,
-                                OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
-                                WavenumberWingHW=None, WavenumberGrid=None, Diluent={}, EnvDependences=None):
-    """Absorption coefficient with the Voigt profile; same inputs/outputs as misc/hapi.py:10906-11141.
-
-    Returns (Omegas, Xsect) as float64 NumPy arrays. The sum over lines runs on the GPU
-    (rtx_line_prep + rtx_voigt_sum); line strengths are carried in fp32 with a power-of-two scale,
-    so Xsect agrees with the reference to ~1e-6 relative, not bit for bit.
-    Not supported (raises): EnvDependences hooks, diluents other than air/self, non-uniform grids.
-    """
+def _absorption_coefficient(profile, Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep, OmegaWing,
+                            IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format, OmegaGrid,
+                            WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid, Diluent,
+                            EnvDependences):
+    """Common body of absorptionCoefficient_Voigt / _Lorentz / _Doppler (they share getDefaultValuesForXsect, the
+    abundance bookkeeping and the per-line prologue; misc/hapi.py:10906-11141, 11144-11375, 11384-11559)."""
     if WavenumberRange is not None: OmegaRange = WavenumberRange
     if WavenumberStep: OmegaStep = WavenumberStep
     if WavenumberWing: OmegaWing = WavenumberWing
@@ -136,7 +129,7 @@ def absorptionCoefficient_Voigt(Components=None, SourceTables=None, partitionFun
         OmegaWing = 0.0
     if not Format:
         Format = "%.12f %e"
-    if OmegaStep > 0.1:
+    if OmegaStep > (0.005 if profile == 2 else 0.1):  # :11027 / :11452
         print("WARNING: Big wavenumber step: possible accuracy decline")
     if OmegaGrid is not None:
         Omegas = np.sort(np.asarray(OmegaGrid, dtype=np.float64))
@@ -153,6 +146,8 @@ def absorptionCoefficient_Voigt(Components=None, SourceTables=None, partitionFun
         NATURAL[(M, I)] = nat
     factor = 1.0 if HITRAN_units else volumeConcentration(p, T)
     GammaL = GammaL.lower()
+    if profile == 2:
+        Diluent = {"air": 1.0 if LineShift else 0.0}  # Doppler: Shift0 = delta_air*p, or none (misc/hapi.py:11510-11513)
     if not Diluent:
         if GammaL == "gamma_air":
             Diluent = {"air": 1.0}
@@ -181,10 +176,62 @@ def absorptionCoefficient_Voigt(Components=None, SourceTables=None, partitionFun
         out = torch.empty((1, grid.n), dtype=torch.float64, device=engine.device())
         engine.voigt_sum(tbl, grid, [T], [p], w, out_f64=out, dil_air=dil.get("air", 0.0), dil_self=dil.get("self", 0.0),
                          omega_wing=OmegaWing, omega_wing_hw=OmegaWingHW, intensity_threshold=IntensityThreshold,
-                         scale=scale, partitionFunction=partitionFunction)
+                         scale=scale, partitionFunction=partitionFunction, profile=profile)
         Xsect = out[0].cpu().numpy()
     if File:
         with open(File, "w") as f:
             for o, x in zip(Omegas, Xsect):
                 f.write((Format % (o, x)) + "\n")
     return Omegas, Xsect
+
+
+def absorptionCoefficient_Voigt(Components=None, SourceTables=None, partitionFunction=PYTIPS, Environment=None,
+                                OmegaRange=None, OmegaStep=None, OmegaWing=None,
+                                IntensityThreshold=DefaultIntensityThreshold, OmegaWingHW=DefaultOmegaWingHW,
+                                GammaL="gamma_air", HITRAN_units=True, LineShift=True, File=None, Format=None,
+                                OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
+                                WavenumberWingHW=None, WavenumberGrid=None, Diluent={}, EnvDependences=None):
+    """Absorption coefficient with the Voigt profile; same inputs/outputs as misc/hapi.py:10906-11141.
+
+    Returns (Omegas, Xsect) as float64 NumPy arrays. The sum over lines runs on the GPU
+    (rtx_line_prep + rtx_voigt_sum); line strengths are carried in fp32 with a power-of-two scale,
+    so Xsect agrees with the reference to ~1e-6 relative, not bit for bit.
+    Not supported (raises): EnvDependences hooks, diluents other than air/self, non-uniform grids.
+    """
+    return _absorption_coefficient(0, Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep, OmegaWing,
+                                   IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format, OmegaGrid,
+                                   WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid, Diluent,
+                                   EnvDependences)
+
+
+def absorptionCoefficient_Lorentz(Components=None, SourceTables=None, partitionFunction=PYTIPS, Environment=None,
+                                  OmegaRange=None, OmegaStep=None, OmegaWing=None,
+                                  IntensityThreshold=DefaultIntensityThreshold, OmegaWingHW=DefaultOmegaWingHW,
+                                  GammaL="gamma_air", HITRAN_units=True, LineShift=True, File=None, Format=None,
+                                  OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
+                                  WavenumberWingHW=None, WavenumberGrid=None, Diluent={}, EnvDependences=None):
+    """Absorption coefficient with the Lorentz profile; same inputs/outputs as misc/hapi.py:11144-11375
+    (PROFILE_LORENTZ :10150, wing max(OmegaWing, OmegaWingHW*Gamma0) :11364). GPU path and limits as for Voigt."""
+    return _absorption_coefficient(1, Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep, OmegaWing,
+                                   IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format, OmegaGrid,
+                                   WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid, Diluent,
+                                   EnvDependences)
+
+
+def absorptionCoefficient_Doppler(Components=None, SourceTables=None, partitionFunction=PYTIPS, Environment=None,
+                                  OmegaRange=None, OmegaStep=None, OmegaWing=None,
+                                  IntensityThreshold=DefaultIntensityThreshold, OmegaWingHW=DefaultOmegaWingHW,
+                                  ParameterBindings=None, EnvironmentDependencyBindings=None,
+                                  GammaL="dummy", HITRAN_units=True, LineShift=True, File=None, Format=None,
+                                  OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
+                                  WavenumberWingHW=None, WavenumberGrid=None):
+    """Absorption coefficient with the Doppler (Gauss) profile; same inputs/outputs as misc/hapi.py:11384-11559
+    (PROFILE_DOPPLER :10160, its own GammaD constants :11534-11538, wing max(OmegaWing, OmegaWingHW*GammaD) :11540,
+    shift delta_air*p only when LineShift). ParameterBindings / EnvironmentDependencyBindings are accepted and ignored,
+    as in the reference. Values below exp(-225) of a line's peak (|nu - nu0| > 18 GammaD) come out 0."""
+    return _absorption_coefficient(2, Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep, OmegaWing,
+                                   IntensityThreshold, OmegaWingHW, "gamma_air", HITRAN_units, LineShift, File, Format, OmegaGrid,
+                                   WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid, {}, None)
+
+
+absorptionCoefficient_Gauss = absorptionCoefficient_Doppler  # misc/hapi.py:11561

@@ -513,3 +513,28 @@ def test_reduce_resolution_full_size_float32_device_path():
     sel = (xo >= xw[0]) & (xo <= xw[-1])
     want = ref.reduceResolution(X[lo:hi], Y[lo:hi].astype(np.float64), 0.25, X_out=xo[sel])
     assert rel_err(out[0][sel], want) < 1e-10
+
+
+# --------------------------------------------------------------------- G10 Lorentz / Doppler
+def test_g10_lorentz_doppler_golden(hapi, golden):
+    """hapi.absorptionCoefficient_Lorentz / _Doppler (rtx_line_prep_profile + the Voigt line-sum kernels) against the
+    reference run. Lorentz is exactly the line-sum's far-wing rational; Doppler is the Voigt profile at y = 0."""
+    g = golden("g10_lorentz_doppler.npz")
+    tbl = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    hapi.storage2cache_from_columns("g10", tbl)
+    gl = np.linspace(float(g["gl_lo"]), float(g["gl_hi"]), int(g["gl_n"]))
+    gd = np.linspace(float(g["gd_lo"]), float(g["gd_hi"]), int(g["gd_n"]))
+    for tag in ("l01", "l32"):
+        om, xs = hapi.absorptionCoefficient_Lorentz(SourceTables="g10", Environment={"T": float(g["T_" + tag]), "p": float(g["p_" + tag])},
+                                                    OmegaGrid=gl)
+        assert np.array_equal(om, gl) and rel_err(xs, g["lor_" + tag]) <= TOL_L, tag
+    _, xs = hapi.absorptionCoefficient_Lorentz(Components=[(1, 1), (2, 1, 0.5)], SourceTables="g10", Environment={"T": 250.0, "p": 0.4},
+                                               OmegaGrid=gl[5000:12000], HITRAN_units=False, OmegaWing=1.0, OmegaWingHW=20.0,
+                                               Diluent={"air": 0.7, "self": 0.3})
+    assert rel_err(xs, g["lor_opt"]) <= TOL_L
+    for tag, (Tk, pk) in (("a", (296.0, 1.0)), ("b", (220.0, 0.05))):
+        _, xs = hapi.absorptionCoefficient_Doppler(SourceTables="g10", Environment={"T": Tk, "p": pk}, OmegaGrid=gd)
+        assert rel_err(xs, g["dop_" + tag]) <= TOL_L, tag
+    _, xs = hapi.absorptionCoefficient_Gauss(SourceTables="g10", Environment={"T": 296.0, "p": 1.0}, OmegaGrid=gd, LineShift=False,
+                                             HITRAN_units=False, OmegaWing=0.05)
+    assert rel_err(xs, g["dop_noshift"]) <= TOL_L

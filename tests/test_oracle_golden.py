@@ -163,3 +163,23 @@ def test_g9_smooth_and_reduce_resolution(golden):
     assert np.allclose(ref.reduceResolution(g["Xf"], g["Y2"], 0.05, X_out=g["Xo"]), g["Yo2"], rtol=1e-11, atol=0)
     Xo8, Yo8 = ref.reduceResolution(g["Xf"], g["Y1"], 0.02, N=8, window="blackman")
     assert Xo8.shape == g["Xo8"].shape and np.allclose(Yo8, g["Yo8"], rtol=1e-11, atol=0)
+
+
+def test_g10_lorentz_doppler(golden):
+    """Oracle restatements of absorptionCoefficient_Lorentz / _Doppler against the reference run."""
+    g = golden("g10_lorentz_doppler.npz")
+    tbl = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    gl = np.linspace(float(g["gl_lo"]), float(g["gl_hi"]), int(g["gl_n"]))
+    gd = np.linspace(float(g["gd_lo"]), float(g["gd_hi"]), int(g["gd_n"]))
+    for tag in ("l01", "l32"):
+        _, xs = ref.absorptionCoefficient_Lorentz(tbl, T=float(g["T_" + tag]), p=float(g["p_" + tag]), OmegaGrid=gl)
+        close(xs, g["lor_" + tag], rtol=1e-11, atol=1e-40)
+    _, xs = ref.absorptionCoefficient_Lorentz(tbl, Components=[(1, 1), (2, 1, 0.5)], T=250.0, p=0.4, OmegaGrid=gl[5000:12000],
+                                              HITRAN_units=False, OmegaWing=1.0, OmegaWingHW=20.0,
+                                              Diluent={"air": 0.7, "self": 0.3})
+    close(xs, g["lor_opt"], rtol=1e-11, atol=1e-30)
+    for tag, (Tk, pk) in (("a", (296.0, 1.0)), ("b", (220.0, 0.05))):
+        _, xs = ref.absorptionCoefficient_Doppler(tbl, T=Tk, p=pk, OmegaGrid=gd)
+        close(xs, g["dop_" + tag], rtol=1e-10, atol=1e-40)
+    _, xs = ref.absorptionCoefficient_Doppler(tbl, LineShift=False, T=296.0, p=1.0, OmegaGrid=gd, HITRAN_units=False, OmegaWing=0.05)
+    close(xs, g["dop_noshift"], rtol=1e-10, atol=1e-30)
