@@ -135,12 +135,17 @@ __device__ __forceinline__ void band_row(const ScArgs& a, const LineRec64* __res
         rden = 1.0f;
       }
     }
-    if (!CORE64 && wz) {
+    if (!CORE64) {
       // pressure-broadened lines (y >= 6: ~70 % of the band lines of C3): the whole band has |z| >= 6 and the
-      // 6-term asymptotic series agrees with Weideman-24 to 6.4e-8; Weideman itself only for y < 6
-      if (RTX_SC_ASYM && q.y >= 6.0f) num = q.A * asym6_re(x, q.y);
-      else num = q.A * weideman_re<float>(x, q.y);
-      rden = 1.0f;
+      // 6-term asymptotic series agrees with Weideman-24 to 6.4e-8. For 1 <= y < 6 the series needs |z| >= 8
+      // (2e-8; the error relative to Re w grows as y -> 0): a row none of whose band lanes is closer than that --
+      // the outer rows of a wide band -- takes the series too; Weideman itself only for the rows around the centre.
+      const bool series = RTX_SC_ASYM && (q.y >= 6.0f || __ballot(wz && fmaf(x, x, q.y * q.y) < 64.0f) == 0ull);
+      if (wz) {
+        if (series) num = q.A * asym6_re(x, q.y);
+        else num = q.A * weideman_re<float>(x, q.y);
+        rden = 1.0f;
+      }
     }
     if (CORE64) {  // this pass adds ONLY the band lanes of small-y lines
       num = in_band ? num : 0.f;
