@@ -179,6 +179,7 @@ struct TudArgs {
 //   |y| <  1/8 : 1 - 2^y = -y*ln2*(1 + z/2 + z^2/6 + z^3/24 + z^4/120), z = y ln2   (truncation 7e-9)
 //   |y| >= 1/8 : 1 - v_exp_f32(y)                                                    (relative error <= 7e-7)
 #define TUD_THIN_Y 0.125f
+#define TUD_OPAQUE_Y 26.0f
 __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
   const float q = fmaf(fmaf(fmaf(fmaf(1.3333558146e-3f, y, 9.6181291076e-3f), y, 5.5504108665e-2f), y, 2.4022650696e-1f), y,
                        6.9314718056e-1f);  // ln2^5/120, ln2^4/24, ln2^3/6, ln2^2/2, ln2
@@ -189,6 +190,7 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 // inside as NA independent recurrences held in registers (full ILP, no dependence between streams). One
 // wave-uniform decision per (wave, layer) -- every lane thick / every lane thin / mixed -- picks the cheapest
 // exact form for all NA streams of that layer, so the scalar unit sees ~10 instructions per layer, not per stream.
+//   opaque: every stream has t <= 2^-26:  L <- B            (1 VALU per stream; most of an opaque band)
 //   thick : t = 2^y,             L <- t (L - B) + B          (the fp32 form of :372, 4 VALU per stream)
 //   thin  : e = em_thin(y),      L <- L + e (B - L)
 //   mixed : e = per-lane select, L <- L + e (B - L)
@@ -235,6 +237,24 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   const float c0 = a.mu_c[0];
   float s0 = 0.f, S0 = 0.f, Lu0 = 0.f;
   float acc = 0.f;
+  // Opaque columns. Downwelling at the surface is blind to everything above the lowest slab whose NADIR transmittance
+  // is <= 2^-26 (what enters it from above reaches the surface attenuated to < 1.5e-8 of itself, in every stream): find
+  // the top of that slab for the whole wave and start the recurrences there. Likewise L-up at the sensor stops
+  // collecting once the path above a layer has t <= 2^-26 in every lane. In an absorption band this leaves a few
+  // layers at either end of the column; the layers in between only add their OD to the tau sum. In a window
+  // (no such slab) the scan costs one extra pass of loads and adds.
+  int k_start = nd - 1;
+  {
+    float S = 0.f;
+    for (int k = 0; k < nd; ++k) {
+      S += od_col[(size_t)k * a.ld];
+      if (__ballot(S * a.ang_cmin >= TUD_OPAQUE_Y) == ~0ull) {
+        k_start = k;
+        break;
+      }
+    }
+  }
+  bool up_live = true;  // wave-uniform
   for (int a0 = 0; a0 < a.n_ang; a0 += NA) {
     float L[NA], cth[NA];
 #pragma unroll
@@ -252,20 +272,28 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
       const float od = od_1;
       od_1 = od_2;
       od_2 = od_col[(size_t)(k >= 2 ? k - 2 : 0) * a.ld];
+      const bool streams = k <= k_start;                    // wave-uniform (k_start < nd)
+      const bool up = a0 == 0 && up_live && k < cnt0;       // wave-uniform
+      if (a0 == 0 && ((a.mask[0][k >> 5] >> (k & 31)) & 1u)) s0 += od;
+      if (!streams && !up) continue;
       const float B = planck_f32(c1x3, x, a.c2l2e_over_T[k]);
-      if (a0 == 0) {
-        if ((a.mask[0][k >> 5] >> (k & 31)) & 1u) s0 += od;
-        if (k < cnt0) {
-          const float y = od * c0;
-          const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
-          Lu0 = fmaf(e * B, __builtin_amdgcn_exp2f(S0 * c0), Lu0);
-          S0 += od;
-        }
-        if (k >= nd) continue;
+      if (up) {
+        const float y = od * c0;
+        const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
+        Lu0 = fmaf(e * B, __builtin_amdgcn_exp2f(S0 * c0), Lu0);
+        S0 += od;
+        if (__ballot(S0 * c0 <= -TUD_OPAQUE_Y) == ~0ull) up_live = false;  // c0 < 0
       }
+      if (!streams) continue;
       const bool thick = od * c_min >= TUD_THIN_Y;  // even the nadir stream has |y| >= 1/8
       const bool thin = od * c_max < TUD_THIN_Y;    // even the most oblique stream has |y| < 1/8
-      if (__ballot(thick) == ~0ull) {
+      // opaque: even the most transparent (nadir) stream has t <= 2^-26: t (L - B) is below half an ulp of B for
+      // |L - B| <= 2 B ... and at most 1.5e-8 |L - B| otherwise -- the layer simply replaces L by B
+      const bool opaque = od * c_min >= TUD_OPAQUE_Y;
+      if (__ballot(opaque) == ~0ull) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) L[q] = B;
+      } else if (__ballot(thick) == ~0ull) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
           const float t = __builtin_amdgcn_exp2f(od * cth[q]);
