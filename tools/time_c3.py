@@ -11,11 +11,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--n", type=int, default=5500000)
 ap.add_argument("--layers", type=int, default=32)
+ap.add_argument("--mf-scale", type=float, default=1.0, help="scale the mixing ratios (1e-4: an optically thin column, tau ~ 0.5-1 between lines)")
 args = ap.parse_args()
 lib = _lib.load()
 full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
 A = synthetic.load_standard_atmosphere()[:args.layers]
-atm = dict(Zs=A[:, 1], Ts=A[:, 5], Ps=A[:, 4], PLs=A[:, 3], MFs_VAL=A[:, 6:8] * 1e6, MFs_ID=np.array([1, 2]))
+atm = dict(Zs=A[:, 1], Ts=A[:, 5], Ps=A[:, 4], PLs=A[:, 3], MFs_VAL=A[:, 6:8] * 1e6 * args.mf_scale, MFs_ID=np.array([1, 2]))
 lines = engine.LineTable(full)
 grid = engine.Grid(500.0, 6000.0, args.n)
 T, Z = atm["Ts"], atm["Zs"]
