@@ -195,8 +195,10 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 //   thin  : e = em_thin(y),      L <- L + e (B - L)
 //   mixed : e = per-lane select, L <- L + e (B - L)
 // OD is read once per block of streams, coalesced along the wavenumber axis.
+#define TUD_STAGE 8
 template <int NA>
 __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
+  __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots: no barrier
   const long long i_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i_raw < a.g.n;
   const long long i = live ? i_raw : a.g.n - 1;  // dead lanes shadow the last point: ballots stay wave-wide
@@ -246,11 +248,20 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   int k_start = nd - 1;
   {
     float S = 0.f;
-    for (int k = 0; k < nd; ++k) {
-      S += od_col[(size_t)k * a.ld];
-      if (__ballot(S * a.ang_cmin >= TUD_OPAQUE_Y) == ~0ull) {
-        k_start = k;
-        break;
+    bool found = false;
+    for (int k0 = 0; k0 < nd && !found; k0 += 8) {  // 8 independent loads in flight per step, not one per layer
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = od_col[(size_t)(k0 + t < nd ? k0 + t : nd - 1) * a.ld];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (!found && k0 + t < nd) {
+          S += v[t];
+          if (__ballot(S * a.ang_cmin >= TUD_OPAQUE_Y) == ~0ull) {
+            k_start = k0 + t;
+            found = true;
+          }
+        }
       }
     }
   }
@@ -263,15 +274,22 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
       cth[q] = a.ang_c[a0 + q];  // slots past n_ang_real hold the weight-0 nadir stream
     }
     const float c_min = a.ang_cmin, c_max = a.ang_cmax;  // |c| range over the streams (nadir .. most oblique)
-    // the OD loads run two layers ahead of their use: with ~4 waves per SIMD a load issued where it is
-    // needed leaves its whole latency exposed once per layer
+    // OD is fetched TUD_STAGE layers at a time: the loads of the next chunk are issued before the current chunk is
+    // worked through (8 layers of arithmetic cover the HBM latency; a register rotated one layer ahead does not --
+    // the copy that rotates it has to wait for the load) and handed over through the thread's own LDS slots, so the
+    // layer loop stays one run-time loop with one copy of the stream code.
     const int k_top = (a0 == 0 ? nL : nd) - 1;
-    float od_1 = k_top >= 0 ? od_col[(size_t)k_top * a.ld] : 0.f;
-    float od_2 = k_top >= 1 ? od_col[(size_t)(k_top - 1) * a.ld] : 0.f;
-    for (int k = k_top; k >= 0; --k) {
-      const float od = od_1;
-      od_1 = od_2;
-      od_2 = od_col[(size_t)(k >= 2 ? k - 2 : 0) * a.ld];
+    float nxt[TUD_STAGE];
+#pragma unroll
+    for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(k_top - t > 0 ? k_top - t : 0) * a.ld];
+    for (int kc = k_top; kc >= 0; kc -= TUD_STAGE) {
+#pragma unroll
+      for (int t = 0; t < TUD_STAGE; ++t) s_stage[t][threadIdx.x] = nxt[t];
+#pragma unroll
+      for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(kc - TUD_STAGE - t > 0 ? kc - TUD_STAGE - t : 0) * a.ld];
+      const int k_lo = kc - TUD_STAGE + 1 > 0 ? kc - TUD_STAGE + 1 : 0;
+    for (int k = kc; k >= k_lo; --k) {
+      const float od = s_stage[kc - k][threadIdx.x];
       const bool streams = k <= k_start;                    // wave-uniform (k_start < nd)
       const bool up = a0 == 0 && up_live && k < cnt0;       // wave-uniform
       if (a0 == 0 && ((a.mask[0][k >> 5] >> (k & 31)) & 1u)) s0 += od;
@@ -313,6 +331,7 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
           L[q] = fmaf(e, B - L[q], L[q]);
         }
       }
+    }
     }
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
