@@ -6,6 +6,8 @@ Tolerances (SURVEY.md 8d, fp64 reference -> fp32 engine):
     transmittance                   : |dtau| <= 2e-6 absolute
     fp64 entry points (planckian)   : 1e-12 relative
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -538,3 +540,47 @@ def test_g10_lorentz_doppler_golden(hapi, golden):
     _, xs = hapi.absorptionCoefficient_Gauss(SourceTables="g10", Environment={"T": 296.0, "p": 1.0}, OmegaGrid=gd, LineShift=False,
                                              HITRAN_units=False, OmegaWing=0.05)
     assert rel_err(xs, g["dop_noshift"]) <= TOL_L
+
+
+# --------------------------------------------------------------------- alternative line-sum formulations
+@pytest.mark.parametrize("kernel", ["scatter", "gather"])
+def test_alternative_line_sum_kernels_agree(kernel):
+    """RADTXFR_VOIGT_KERNEL=scatter|gather (kept for A/B timing and as cross-checks of the default nodal kernel) give
+    the same layer optical depths: a child process per formulation (the choice is read once per process), compared
+    with the default formulation computed here and with the oracle."""
+    import subprocess
+    import sys
+    import tempfile
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from radtxfr_amd import synthetic, radiative_transfer as rt\n"
+        "full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)\n"
+        "sub = synthetic.subset_table(full, 988.0, 1016.0)\n"
+        "a = synthetic.c3_atmosphere(32)\n"
+        "od = np.stack([rt.compute_OD(1000.0, 1004.0, DVOUT=0.001, line_table=sub, T=a['Ts'][k], P=a['Ps'][k], PL=a['PLs'][k],\n"
+        "                             MF_VAL=a['MFs_VAL'][k], MF_ID=a['MFs_ID'])[1] for k in (0, 31)], 1)\n"
+        "np.save(sys.argv[1], od)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "od.npy")
+        env = dict(os.environ, RADTXFR_VOIGT_KERNEL=kernel)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+        od_alt = np.load(out)
+    from radtxfr_amd import radiative_transfer as rt
+
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    sub = synthetic.subset_table(full, 988.0, 1016.0)
+    a = synthetic.c3_atmosphere(32)
+    X = None
+    cols = []
+    want = []
+    for k in (0, 31):
+        X, od = rt.compute_OD(1000.0, 1004.0, DVOUT=0.001, line_table=sub, T=a["Ts"][k], P=a["Ps"][k], PL=a["PLs"][k],
+                              MF_VAL=a["MFs_VAL"][k], MF_ID=a["MFs_ID"])
+        cols.append(od)
+        want.append(ref.layer_od(sub, X, a["Ts"][k], a["Ps"][k], a["PLs"][k], a["MFs_VAL"][k], a["MFs_ID"]))
+    od_def = np.stack(cols, 1)
+    assert rel_err(od_alt, od_def) <= 2e-6, kernel     # formulations differ only in fp32 summation order / interpolation
+    assert rel_err(od_alt, np.stack(want, 1)) <= TOL_L, kernel
