@@ -235,3 +235,30 @@ def absorptionCoefficient_Doppler(Components=None, SourceTables=None, partitionF
 
 
 absorptionCoefficient_Gauss = absorptionCoefficient_Doppler  # misc/hapi.py:11561
+
+
+def absorptionCoefficient_SDVoigt(Components=None, SourceTables=None, partitionFunction=PYTIPS, Environment=None,
+                                  OmegaRange=None, OmegaStep=None, OmegaWing=None,
+                                  IntensityThreshold=DefaultIntensityThreshold, OmegaWingHW=DefaultOmegaWingHW,
+                                  GammaL="gamma_air", HITRAN_units=True, LineShift=True, File=None, Format=None,
+                                  OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
+                                  WavenumberWingHW=None, WavenumberGrid=None, Diluent={}, EnvDependences=None):
+    """Speed-dependent Voigt, signature of misc/hapi.py:10657-10904 -- for tables WITHOUT speed-dependence columns.
+
+    The reference reads SD_air / SD_self (:10884-10890); a table that lacks them (the 160-character HITRAN .par
+    format has none) gives Gamma2 = Shift2 = 0, for which pcqsdhc takes its PART1 branch (:9908-9915), i.e. the Voigt
+    profile: in the reference itself the two functions then agree to 2e-12 (checked in the build container). This
+    shim evaluates that case through the Voigt path; non-zero SD columns raise NotImplementedError (pcqsdhc PART2-4,
+    the quadratic speed dependence, is not implemented on the GPU)."""
+    for name in listOfTuples(SourceTables):
+        if name is None or name not in LOCAL_TABLE_CACHE:
+            continue
+        data = LOCAL_TABLE_CACHE[name]["data"]
+        for col in ("SD_air", "SD_self"):
+            if col in data and np.any(np.asarray(data[col], dtype=np.float64) != 0.0):
+                raise NotImplementedError("absorptionCoefficient_SDVoigt: table %r has non-zero %s (speed dependence is not "
+                                          "implemented; the Voigt limit is)" % (name, col))
+    return _absorption_coefficient(0, Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep, OmegaWing,
+                                   IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format, OmegaGrid,
+                                   WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid, Diluent,
+                                   EnvDependences)

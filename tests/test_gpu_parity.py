@@ -542,6 +542,23 @@ def test_g10_lorentz_doppler_golden(hapi, golden):
     assert rel_err(xs, g["dop_noshift"]) <= TOL_L
 
 
+def test_sdvoigt_is_the_voigt_limit_without_sd_columns(hapi, golden):
+    """hapi.absorptionCoefficient_SDVoigt on a table without SD_* columns is the Voigt profile (misc/hapi.py:9908-9915):
+    same result as the Voigt shim, within tolerance of the reference's Voigt golden; non-zero SD columns are refused."""
+    g = golden("g4_voigt_xsec.npz")
+    grid = _g4_table(hapi, g)[20000:26000]
+    env = {"T": float(g["T_l01"]), "p": float(g["p_l01"])}
+    _, xv = hapi.absorptionCoefficient_Voigt(SourceTables="g4", Environment=env, OmegaGrid=grid)
+    _, xs = hapi.absorptionCoefficient_SDVoigt(SourceTables="g4", Environment=env, OmegaGrid=grid)
+    assert np.array_equal(xs, xv)
+    assert rel_err(xs, g["xs_l01"][20000:26000]) <= TOL_L
+    tbl = dict(synthetic.synth_line_table(7, 50, 900.0, 905.0))
+    tbl["SD_air"] = np.full(50, 0.1)
+    hapi.storage2cache_from_columns("sdv", tbl)
+    with pytest.raises(NotImplementedError):
+        hapi.absorptionCoefficient_SDVoigt(SourceTables="sdv", OmegaGrid=np.linspace(900.0, 905.0, 501))
+
+
 # --------------------------------------------------------------------- alternative line-sum formulations
 @pytest.mark.parametrize("kernel", ["scatter", "gather"])
 def test_alternative_line_sum_kernels_agree(kernel):
