@@ -559,6 +559,32 @@ def test_sdvoigt_is_the_voigt_limit_without_sd_columns(hapi, golden):
         hapi.absorptionCoefficient_SDVoigt(SourceTables="sdv", OmegaGrid=np.linspace(900.0, 905.0, 501))
 
 
+def test_afit_xs_grid_batched_states(hapi, tmp_path):
+    """afit_xs.cross_section_grid / generate_xs_files (the T x p loop of misc/RT_gen_AbsXS_files.py:86-92 as one
+    batched launch): every state equals the per-state hapi shim call and agrees with the oracle; files round-trip."""
+    from radtxfr_amd import afit_xs
+
+    tbl = synthetic.synth_line_table(11, 400, 880.0, 930.0)
+    h2o = {k: np.asarray(v)[np.asarray(tbl["molec_id"]) == 1] for k, v in tbl.items()}
+    hapi.storage2cache_from_columns("H2O", h2o)
+    X = np.linspace(900.0, 910.0, 4001)  # 0.0025 cm^-1, the generator's step
+    T = np.array([275.0, 300.0, 320.0])
+    P = np.array([0.85, 1.05])
+    xs = afit_xs.cross_section_grid("H2O", T, P, X, WavenumberWingHW=350.0)
+    assert xs.shape == (3, 2, 4001)
+    for it, t in enumerate(T):
+        for ip, p in enumerate(P):
+            _, one = hapi.absorptionCoefficient_SDVoigt(SourceTables="H2O", HITRAN_units=True, Environment={"T": t, "p": p},
+                                                        OmegaGrid=X, IntensityThreshold=0, WavenumberWingHW=350)
+            assert rel_err(xs[it, ip], one) <= 1e-6
+    _, want = ref.absorptionCoefficient_Voigt(h2o, T=300.0, p=1.05, OmegaGrid=X, OmegaWingHW=350.0)
+    assert rel_err(xs[1, 1], want) <= TOL_L
+    names = afit_xs.generate_xs_files("H2O", 1, T, P, X, "synthetic", WavenumberWingHW=350.0, directory=str(tmp_path))
+    assert len(names) == 6 and os.path.basename(names[0]) == "XS-01-0275K-086126Pa.bin"
+    back = afit_xs.AFIT_XS_read(names[3])  # T = 300, p = 1.05
+    assert back["T"] == 300.0 and abs(back["P"] - 101325 * 1.05) < 1e-6 and np.array_equal(back["Y"], xs[1, 1])
+
+
 # --------------------------------------------------------------------- alternative line-sum formulations
 @pytest.mark.parametrize("kernel", ["scatter", "gather"])
 def test_alternative_line_sum_kernels_agree(kernel):

@@ -243,3 +243,26 @@ def test_window_taps_reproduce_the_reference_smoother():
         t, c = engine.window_taps(wl, win, symmetric=True)
         assert len(t) % 2 == 1 and np.allclose(t, t[::-1])
         assert np.allclose(fir(x, t, c), cpu_ref.smooth_sym(x, wl, win), rtol=0, atol=1e-14)
+
+
+def test_afit_xs_file_format(tmp_path):
+    """AFIT_XS binary layout of misc/RT_gen_AbsXS_files.py:45-83 (b'v1', six float64, 128-byte description, float64
+    data; default name XS-ID-TTTTK-PPPPPPPa.bin), checked against the same NumPy dtypes the reference serialises."""
+    from radtxfr_amd import afit_xs
+
+    X = np.linspace(400.0, 410.0, 4001)
+    Y = np.random.default_rng(0).random(4001).astype(np.float32)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        fn = afit_xs.AFIT_XS_write(X, Y, 275.0, 101325 * 0.85, 1, "HITRAN2016 - HAPI - SDVoigt")
+    finally:
+        os.chdir(cwd)
+    assert fn == "XS-01-0275K-086126Pa.bin"
+    raw = open(os.path.join(tmp_path, fn), "rb").read()
+    want = (np.array("v1", "<S2").tobytes() + np.array([X.min(), X.max(), X.size, 1, 275.0, 101325 * 0.85], "<f8").tobytes()
+            + np.array("HITRAN2016 - HAPI - SDVoigt", "<S128").tobytes() + Y.astype("<f8").tobytes())
+    assert raw == want and len(raw) == 2 + 48 + 128 + 8 * 4001
+    back = afit_xs.AFIT_XS_read(os.path.join(tmp_path, fn))
+    assert back["ID"] == 1 and back["T"] == 275.0 and back["n"] == 4001 and back["db"] == "HITRAN2016 - HAPI - SDVoigt"
+    assert np.array_equal(back["Y"], Y.astype(np.float64)) and np.allclose(back["X"], X, rtol=0, atol=1e-12)
