@@ -50,7 +50,9 @@ __device__ __forceinline__ double grid_x(const GridDev& g, long long ig) {
 // neighbouring tiles share their line records in that XCD's L2; the chunks are dealt round-robin over the XCDs, so
 // every XCD sees the whole spectrum. (One contiguous eighth of the spectrum per XCD left the XCD with the highest
 // wavenumbers -- widest Doppler cores, most Weideman rows -- as the straggler of every launch.)
+#ifndef RTX_XCD_CHUNK
 #define RTX_XCD_CHUNK 16
+#endif
 __device__ __forceinline__ int xcd_tile(int b) {
   const int idx = b >> 3, c = idx / RTX_XCD_CHUNK, w = idx - c * RTX_XCD_CHUNK;
   return (c * 8 + (b & 7)) * RTX_XCD_CHUNK + w;

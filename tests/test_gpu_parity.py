@@ -457,6 +457,9 @@ def test_full_c3_width_properties():
         d = ((OD1 - ref_slice).abs() / ref_slice.abs().clamp_min(1e-3 * float(ref_slice.max()))).max()
         assert float(d) <= 1e-6, float(d)
     assert float(((OD2 - 2.0 * OD1).abs() / (2.0 * OD1).clamp_min(1e-30)).max()) <= 1e-6
+    # run-to-run determinism: no atomics, fixed summation order -> the same bits every time
+    OD1b = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    assert torch.equal(OD1, OD1b), "the line-sum is not bit-reproducible from run to run"
     # (4) oracle on a 3000-point window of the full grid
     i0, n = 1234567, 3000
     Xw = grid.axis()[i0:i0 + n]
