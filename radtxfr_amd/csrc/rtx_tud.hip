@@ -163,6 +163,7 @@ struct TudArgs {
   int n_ang_real;
   float inv_wsum;                      // 1/sum(cos*sin) (inf/NaN propagate like the reference's 0/0)
   double c2l2e_over_T[TUD_MAX_LAYERS]; // 100*c2*log2(e)/T_k
+  double c2l2e_over_Tmax, c2l2e_over_Tmin;  // the same for the warmest / coldest layer of the column
   float ang_c[TUD_MAX_ANGLES];         // -log2(e)/cos(theta)
   float ang_w[TUD_MAX_ANGLES];         // cos(theta)*sin(theta)
   float ang_cmin, ang_cmax;            // min / max of |ang_c| over the evaluated streams
@@ -193,7 +194,7 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 //   opaque: every stream has t <= 2^-26:  L <- B            (1 VALU per stream; most of an opaque band)
 //   thick : t = 2^y,             L <- t (L - B) + B          (the fp32 form of :372, 4 VALU per stream)
 //   thin  : e = em_thin(y),      L <- L + e (B - L)
-//   mixed : e = per-lane select, L <- L + e (B - L)
+//   mixed : per lane, the thin form where |y| < 1/8 and the thick form elsewhere
 // OD is read once per block of streams, coalesced along the wavenumber axis.
 #define TUD_STAGE 8
 template <int NA>
@@ -220,8 +221,9 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
       if (k < cnt) {
         const float B = planck_f32(c1x3, x, a.c2l2e_over_T[k]);
         const float y = od * c;
-        const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
-        Lu = fmaf(e, B - Lu, Lu);  // t*Lu + (1-t)*B
+        // t*Lu + (1-t)*B: thin lanes through the emissivity, thick lanes through the transmittance (the other way
+        // round each form cancels: L + e (B - L) with e ~ 1, or t (L - B) + B with t ~ 1)
+        Lu = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - Lu, Lu) : fmaf(__builtin_amdgcn_exp2f(y), Lu - B, B);
       }
     }
     if (live) {
@@ -239,8 +241,17 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   const float c0 = a.mu_c[0];
   float s0 = 0.f, S0 = 0.f, Lu0 = 0.f;
   float acc = 0.f;
+  // How opaque is opaque: what is dropped is at most (transmittance) x (the largest Planck radiance of the column), what
+  // is kept is at least of the order of the smallest one, so the transmittance has to be 2^-26 of the RATIO of the two
+  // -- at 6000 cm^-1 between 190 K and 310 K that ratio is 4e7, at 700 cm^-1 it is 8.
+  float y_opq;
+  {
+    const float b_hot = planck_f32(c1x3, x, a.c2l2e_over_Tmax), b_cold = planck_f32(c1x3, x, a.c2l2e_over_Tmin);
+    const float r = __builtin_amdgcn_logf(b_hot / b_cold);  // log2
+    y_opq = (b_cold > 0.f && r == r && r < 1e30f) ? TUD_OPAQUE_Y + 1.0f + fmaxf(r, 0.f) : 3.0e38f;
+  }
   // Opaque columns. Downwelling at the surface is blind to everything above the lowest slab whose NADIR transmittance
-  // is <= 2^-26 (what enters it from above reaches the surface attenuated to < 1.5e-8 of itself, in every stream): find
+  // is <= 2^-y_opq (what enters it from above reaches the surface attenuated to < 1.5e-8 of the column's own emission, in every stream): find
   // the top of that slab for the whole wave and start the recurrences there. Likewise L-up at the sensor stops
   // collecting once the path above a layer has t <= 2^-26 in every lane. In an absorption band this leaves a few
   // layers at either end of the column; the layers in between only add their OD to the tau sum. In a window
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
       for (int t = 0; t < 8; ++t) {
         if (!found && k0 + t < nd) {
           S += v[t];
-          if (__ballot(S * a.ang_cmin >= TUD_OPAQUE_Y) == ~0ull) {
+          if (__ballot(S * a.ang_cmin >= y_opq) == ~0ull) {
             k_start = k0 + t;
             found = true;
           }
@@ -300,14 +311,14 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
         const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
         Lu0 = fmaf(e * B, __builtin_amdgcn_exp2f(S0 * c0), Lu0);
         S0 += od;
-        if (__ballot(S0 * c0 <= -TUD_OPAQUE_Y) == ~0ull) up_live = false;  // c0 < 0
+        if (__ballot(S0 * c0 <= -y_opq) == ~0ull) up_live = false;  // c0 < 0
       }
       if (!streams) continue;
       const bool thick = od * c_min >= TUD_THIN_Y;  // even the nadir stream has |y| >= 1/8
       const bool thin = od * c_max < TUD_THIN_Y;    // even the most oblique stream has |y| < 1/8
       // opaque: even the most transparent (nadir) stream has t <= 2^-26: t (L - B) is below half an ulp of B for
       // |L - B| <= 2 B ... and at most 1.5e-8 |L - B| otherwise -- the layer simply replaces L by B
-      const bool opaque = od * c_min >= TUD_OPAQUE_Y;
+      const bool opaque = od * c_min >= y_opq;
       if (__ballot(opaque) == ~0ull) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) L[q] = B;
@@ -327,8 +338,8 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
           const float y = od * cth[q];
-          const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
-          L[q] = fmaf(e, B - L[q], L[q]);
+          // per lane: thin through the emissivity, thick through the transmittance (each form cancels in the other regime)
+          L[q] = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - L[q], L[q]) : fmaf(__builtin_amdgcn_exp2f(y), L[q] - B, B);
         }
       }
     }
@@ -377,10 +388,15 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
   a.OD = OD; a.ld = ld; a.ld_out = ld_out; a.g = to_dev(grid);
   a.n_layers = n_layers; a.n_alt = n_alt; a.n_mu = n_mu; a.n_down = n_down; a.return_od = return_od;
   a.tau = tau; a.Lu = Lu; a.Ld = Ld; a.Ld_ang = Ld_angles;
+  double t_max = 0.0, t_min = 0.0;
   for (int k = 0; k < n_layers; ++k) {
     if (!(T_h[k] > 0.0)) RTX_FAIL("layer %d temperature %g", k, T_h[k]);
     a.c2l2e_over_T[k] = 100.0 * RT_C2 * LOG2E / T_h[k];
+    if (k == 0 || T_h[k] > t_max) t_max = T_h[k];
+    if (k == 0 || T_h[k] < t_min) t_min = T_h[k];
   }
+  a.c2l2e_over_Tmax = 100.0 * RT_C2 * LOG2E / t_max;
+  a.c2l2e_over_Tmin = 100.0 * RT_C2 * LOG2E / t_min;
   for (int ia = 0; ia < n_alt; ++ia) {
     int c = 0;
     for (int k = 0; k < n_layers; ++k)

@@ -630,3 +630,88 @@ def test_alternative_line_sum_kernels_agree(kernel):
     od_def = np.stack(cols, 1)
     assert rel_err(od_alt, od_def) <= 2e-6, kernel     # formulations differ only in fp32 summation order / interpolation
     assert rel_err(od_alt, np.stack(want, 1)) <= TOL_L, kernel
+
+
+# --------------------------------------------------------------------- TUD: randomised configurations
+def test_tud_random_configurations_vs_oracle():
+    """rtx_tud against the oracle on random columns: 1..70 layers, several sensor altitudes (also non-monotone ones and
+    ones below the surface layer), slant paths, 1..40 angles (more than one block of streams), returnOD, and optical
+    depths whose magnitude changes by layer and along the spectrum so that waves are thin, thick, mixed and opaque --
+    the paths the kernel selects per (wave, layer), the opaque-slab start and the staged OD loads."""
+    import torch
+    from radtxfr_amd import engine
+
+    rng = np.random.default_rng(20261011)
+    for trial in range(24):
+        nL = int(rng.integers(1, 71))
+        n = int(rng.integers(700, 3000))
+        Z = np.sort(rng.uniform(0.0, 60.0, nL))
+        T = rng.uniform(190.0, 310.0, nL)
+        lo = float(rng.uniform(500.0, 5500.0))
+        grid = engine.Grid(lo, lo + 2.0, n)
+        X = grid.axis()
+        # per-layer scale 10^U(-6, 2), smooth spectral structure x a few narrow spikes, some exactly zero columns
+        scale = 10.0 ** rng.uniform(-6.0, 2.0, nL)
+        shape = 1.0 + 0.9 * np.sin(rng.uniform(5, 60) * X + rng.uniform(0, 6))
+        for _ in range(4):
+            c, w = rng.uniform(X[0], X[-1]), 10.0 ** rng.uniform(-3.0, -1.0)
+            shape = shape + rng.uniform(10, 3000) * w * w / ((X - c) ** 2 + w * w)
+        OD = (scale[:, None] * shape[None, :]).astype(np.float32)
+        if trial % 3 == 0:
+            OD[:, rng.integers(0, n, 20)] = 0.0
+        nalt = int(rng.integers(1, 4))
+        alts = rng.uniform(-1.0, 70.0, nalt)
+        if trial % 4 == 1:
+            alts = np.array([500.0])
+        theta = float(rng.choice([0.0, 0.3, 1.1]))
+        nA = int(rng.choice([1, 2, 7, 30, 33, 40]))
+        ret_od = bool(trial % 5 == 2)
+        tau, Lu, Ld, (nZ, nMu) = engine.tud(torch.as_tensor(OD, device="cuda"), grid, T, Z, Altitudes=alts, theta_r=theta,
+                                            N_angle=nA, returnOD=ret_od)
+        tr, ur, dr = ref.tud_from_od(X, OD.astype(np.float64).T, T, Z, Altitudes=alts, theta_r=theta, N_angle=nA, returnOD=ret_od)
+        tau_h = tau.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1).reshape(np.shape(tr))
+        Lu_h = Lu.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1).reshape(np.shape(ur))
+        tag = (trial, nL, nalt, theta, nA, ret_od)
+        if ret_od:
+            assert rel_err(tau_h, tr) <= TOL_L, tag
+        else:
+            assert np.max(np.abs(tau_h - tr)) <= TOL_TAU, tag
+        assert rel_err(Lu_h, ur) <= TOL_L, tag
+        if nA == 1:  # the reference divides 0 by 0 (theta = 0 has weight 0): NaN here too
+            assert np.isnan(dr).all() and bool(torch.isnan(Ld).all()), tag
+        else:
+            assert rel_err(Ld.double().cpu().numpy(), dr) <= TOL_L, tag
+
+
+# --------------------------------------------------------------------- line-sum: randomised grids and states
+def test_line_sum_random_grids_vs_oracle(hapi):
+    """hapi.absorptionCoefficient_Voigt / _Lorentz against the oracle for random grid steps (3e-4 .. 2e-2 cm^-1: Lorentz
+    widths from hundreds of grid points down to a few, i.e. every mix of tile-level, row-level, near and band rows),
+    window placements (ragged last tiles, grids shorter than a tile), temperatures, pressures from 1e-3 to 1.2 atm
+    (y from << 1, the fp64 pass, to >> 15, no band at all), wing settings and diluent mixes."""
+    rng = np.random.default_rng(20261012)
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    for trial in range(10):
+        step = float(10.0 ** rng.uniform(-3.5, -1.7))
+        n = int(rng.integers(300, 9000))
+        lo = float(rng.uniform(500.0, 5990.0 - n * step))
+        grid = np.linspace(lo, lo + (n - 1) * step, n)
+        p = float(10.0 ** rng.uniform(-3.0, 0.08))
+        Tk = float(rng.uniform(190.0, 320.0))
+        hw = float(rng.choice([5.0, 25.0, 50.0]))
+        wing = float(rng.choice([0.0, 0.0, 0.7]))
+        reach = max(wing, hw * 0.12 * max(p, 0.02)) + 1.0
+        sub = synthetic.subset_table(full, grid[0] - reach, grid[-1] + reach)
+        name = "fz%d" % trial
+        hapi.storage2cache_from_columns(name, sub)
+        dil = {"air": 0.8, "self": 0.2} if trial % 3 == 0 else {}
+        kw = dict(SourceTables=name, Environment={"T": Tk, "p": p}, OmegaGrid=grid, OmegaWing=wing, OmegaWingHW=hw, Diluent=dil)
+        okw = dict(T=Tk, p=p, OmegaGrid=grid, OmegaWing=wing, OmegaWingHW=hw, Diluent=dil or None)
+        tag = (trial, step, n, lo, p, Tk, hw, wing)
+        _, xs = hapi.absorptionCoefficient_Voigt(**kw)
+        _, want = ref.absorptionCoefficient_Voigt(sub, **okw)
+        assert rel_err(xs, want) <= TOL_L, ("voigt",) + tag
+        if trial % 2 == 0:
+            _, xs = hapi.absorptionCoefficient_Lorentz(**kw)
+            _, want = ref.absorptionCoefficient_Lorentz(sub, **okw)
+            assert rel_err(xs, want) <= TOL_L, ("lorentz",) + tag
