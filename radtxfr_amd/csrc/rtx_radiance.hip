@@ -142,8 +142,8 @@ extern "C" int rtx_apparent_radiance(const double* X, int64_t nX, const float* e
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ILS. Band b covers the open interval |X - centre_b| < R_b (R = sigma for the triangle; 14 sigma for
-// the Gaussian, beyond which exp(-x^2/2) < 3e-43 of the peak, far below fp32 resolution of the sums).
+// ILS. Band b covers the open interval |X - centre_b| < R_b (R = sigma for the triangle; for the Gaussian the
+// points whose weight is within 3e-43 = exp(-14^2/2) of the largest one, far below fp32 resolution of the sums).
 struct IlsArgs {
   int kind;
   GridDev g;
@@ -170,13 +170,30 @@ __device__ long long ils_bound(const IlsArgs& a, double v, int strict) {
   return lo;
 }
 
-__device__ __forceinline__ float ils_weight(int kind, double x, double c, double s) {
+// z0sq: (distance from the band centre to the nearest grid point / sigma)^2 for a Gaussian band centred OUTSIDE the
+// grid (0 inside). The reference does not clip the Gaussian band list (ILS_MAKO.py:13-19): such a band comes out as the
+// average of the grid's edge region under the far Gaussian tail, as long as its fp64 weights do not all underflow
+// (~38 sigma); weights are taken relative to the nearest point (the common factor cancels in the normalisation).
+__device__ __forceinline__ float ils_weight(int kind, double x, double c, double s, double z0sq = 0.0) {
   if (kind == 0) {
     const float w = 1.0f - fabsf((float)(x - c)) / (float)s;  // tri(), :1236-1239
     return w < 0.f ? 0.f : w;
   }
-  const float z = (float)((x - c) / s);
-  return __expf(-0.5f * z * z) / ((float)s * 2.5066282746310002f);  // g(), ILS_MAKO.py:24
+  const double z = (x - c) / s;
+  return __expf((float)(-0.5 * (z * z - z0sq))) / ((float)s * 2.5066282746310002f);  // g(), ILS_MAKO.py:24
+}
+
+// Support radius of band (c, s) on this grid; for the Gaussian also z0sq (see ils_weight) and whether the reference's
+// weights all underflow to zero (0/0 = NaN there, ILS_MAKO.py:27: an empty support here).
+__device__ __forceinline__ double ils_reach(const IlsArgs& a, double c, double s, double& z0sq, bool& dead) {
+  z0sq = 0.0;
+  dead = false;
+  if (a.kind == 0) return s;
+  const double x0 = ils_x(a, 0), x1 = ils_x(a, a.nx - 1);
+  const double d0 = fmax(fmax(x0 - c, c - x1), 0.0);
+  z0sq = (d0 / s) * (d0 / s);
+  dead = 0.5 * z0sq + log(s * 2.5066282746310002) > 744.44;  // exp(-744.44) = 2^-1074, the smallest denormal
+  return sqrt(d0 * d0 + 196.0 * s * s);  // 14 sigma of relative weight: < 3e-43 of the largest one
 }
 
 // nS small: lanes stride over the band's grid points, every lane handles all nS columns of its rows;
@@ -185,14 +202,16 @@ template <int NS_MAX>
 __global__ __launch_bounds__(256) void ils_points_kernel(IlsArgs a) {
   const int b = blockIdx.x;
   const double c = a.centre[b], s = a.sigma[b];
-  const double R = a.kind == 0 ? s : 14.0 * s;
-  const long long lo = ils_bound(a, c - R, 1), hi = ils_bound(a, c + R, 0);
+  double z0sq;
+  bool dead;
+  const double R = ils_reach(a, c, s, z0sq, dead);
+  const long long lo = dead ? 0 : ils_bound(a, c - R, 1), hi = dead ? 0 : ils_bound(a, c + R, 0);
   float acc[NS_MAX];
   float wsum = 0.f;
 #pragma unroll
   for (int q = 0; q < NS_MAX; ++q) acc[q] = 0.f;
   for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const float w = ils_weight(a.kind, ils_x(a, i), c, s);
+    const float w = ils_weight(a.kind, ils_x(a, i), c, s, z0sq);
     wsum += w;
     const float* y = a.Y + i * a.ldY;
 #pragma unroll
@@ -227,15 +246,17 @@ __global__ __launch_bounds__(256) void ils_columns_kernel(IlsArgs a) {
   const long long col = (long long)blockIdx.y * 64 + (threadIdx.x & 63);
   const int wave = threadIdx.x >> 6;
   const double c = a.centre[b], s = a.sigma[b];
-  const double R = a.kind == 0 ? s : 14.0 * s;
-  const long long lo = ils_bound(a, c - R, 1), hi = ils_bound(a, c + R, 0);
+  double z0sq;
+  bool dead;
+  const double R = ils_reach(a, c, s, z0sq, dead);
+  const long long lo = dead ? 0 : ils_bound(a, c - R, 1), hi = dead ? 0 : ils_bound(a, c + R, 0);
   float acc = 0.f, wsum = 0.f;
   const bool live = col < a.nS;
   for (long long i0 = lo + wave; i0 < hi; i0 += 256) {  // two-level sums (64 rows per block)
     float pa = 0.f, pw = 0.f;
     const long long blk_end = i0 + 256 < hi ? i0 + 256 : hi;
     for (long long i = i0; i < blk_end; i += 4) {
-      const float w = ils_weight(a.kind, ils_x(a, i), c, s);
+      const float w = ils_weight(a.kind, ils_x(a, i), c, s, z0sq);
       pw += w;
       if (live) pa = fmaf(w, a.Y[i * a.ldY + col], pa);
     }
@@ -263,8 +284,10 @@ __global__ __launch_bounds__(256) void ils_columns4_kernel(IlsArgs a) {
   const long long col4 = (long long)blockIdx.y * 64 + lane;  // index of the float4 column group
   const long long nS4 = a.nS >> 2, ld4 = a.ldY >> 2;
   const double c = a.centre[b], s = a.sigma[b];
-  const double R = a.kind == 0 ? s : 14.0 * s;
-  const long long lo = ils_bound(a, c - R, 1), hi = ils_bound(a, c + R, 0);
+  double z0sq;
+  bool dead;
+  const double R = ils_reach(a, c, s, z0sq, dead);
+  const long long lo = dead ? 0 : ils_bound(a, c - R, 1), hi = dead ? 0 : ils_bound(a, c + R, 0);
   const bool live = col4 < nS4;
   const float4* Y4 = reinterpret_cast<const float4*>(a.Y) + (live ? col4 : 0);
   // two-level sums: a wave adds up to ~6000 rows per band; 64-row blocks keep the fp32 error at ~1e-7
@@ -276,14 +299,14 @@ __global__ __launch_bounds__(256) void ils_columns4_kernel(IlsArgs a) {
     float pw = 0.f;
     const long long blk_end = i + 256 < hi ? i + 256 : hi;
     for (; i + 4 < blk_end; i += 8) {  // two rows in flight per wave
-      const float w0 = ils_weight(a.kind, ils_x(a, i), c, s), w1 = ils_weight(a.kind, ils_x(a, i + 4), c, s);
+      const float w0 = ils_weight(a.kind, ils_x(a, i), c, s, z0sq), w1 = ils_weight(a.kind, ils_x(a, i + 4), c, s, z0sq);
       const float4 y0 = Y4[i * ld4], y1 = Y4[(i + 4) * ld4];
       pw += w0 + w1;
       pa.x = fmaf(w0, y0.x, pa.x); pa.y = fmaf(w0, y0.y, pa.y); pa.z = fmaf(w0, y0.z, pa.z); pa.w = fmaf(w0, y0.w, pa.w);
       pa.x = fmaf(w1, y1.x, pa.x); pa.y = fmaf(w1, y1.y, pa.y); pa.z = fmaf(w1, y1.z, pa.z); pa.w = fmaf(w1, y1.w, pa.w);
     }
     for (; i < blk_end; i += 4) {
-      const float w0 = ils_weight(a.kind, ils_x(a, i), c, s);
+      const float w0 = ils_weight(a.kind, ils_x(a, i), c, s, z0sq);
       const float4 y0 = Y4[i * ld4];
       pw += w0;
       pa.x = fmaf(w0, y0.x, pa.x); pa.y = fmaf(w0, y0.y, pa.y); pa.z = fmaf(w0, y0.z, pa.z); pa.w = fmaf(w0, y0.w, pa.w);

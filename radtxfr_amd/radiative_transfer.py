@@ -64,7 +64,8 @@ def _is_torch(x):
 def _dev_f64(x, dev):
     if _is_torch(x):
         return x.to(device=dev, dtype=torch.float64).contiguous()
-    return torch.as_tensor(np.asarray(x, dtype=np.float64), device=dev).contiguous()
+    a = np.asarray(x, dtype=np.float64)
+    return torch.as_tensor(a if a.flags.writeable else a.copy(), device=dev).contiguous()  # read-only views (broadcast_to)
 
 
 def _dev_f32(x, dev):

@@ -715,3 +715,59 @@ def test_line_sum_random_grids_vs_oracle(hapi):
             _, xs = hapi.absorptionCoefficient_Lorentz(**kw)
             _, want = ref.absorptionCoefficient_Lorentz(sub, **okw)
             assert rel_err(xs, want) <= TOL_L, ("lorentz",) + tag
+
+
+# --------------------------------------------------------------------- streaming stages: randomised shapes
+def test_streaming_stages_random_shapes_vs_oracle(rt):
+    """planckian / brightnessTemperature / BT2L, compute_LWIR_apparent_radiance and ILS_MAKO (both variants) against
+    the oracle for random shapes: odd sample counts (the float4 kernels' remainders), 1..9 atmospheres and surface
+    temperatures, with and without dT / return_Ls, grids that clip the band list at either end."""
+    from radtxfr_amd import ILS_MAKO as ilsg
+
+    rng = np.random.default_rng(20261013)
+    for trial in range(8):
+        nX = int(rng.integers(40, 400))
+        X = np.sort(rng.uniform(700.0, 1400.0, nX))
+        nE, nA, nT = int(rng.integers(1, 12)), int(rng.integers(1, 10)), int(rng.integers(1, 6))
+        emis = rng.uniform(0.0, 1.0, (nX, nE))
+        Ts = rng.uniform(250.0, 330.0, nA)
+        tau = rng.uniform(0.0, 1.0, (nX, nA))
+        La = rng.uniform(0.0, 5.0, (nX, nA))
+        Ld = rng.uniform(0.0, 9.0, (nX, nA))
+        dT = rng.uniform(-10.0, 10.0, nT) if trial % 2 else None
+        want = ref.compute_LWIR_apparent_radiance(X, emis, Ts, tau, La, Ld, dT=dT, return_Ls=True)
+        got = rt.compute_LWIR_apparent_radiance(X, emis, Ts, tau, La, Ld, dT=dT, return_Ls=True)
+        for g_, w_ in zip(got, want):
+            assert g_.shape == w_.shape and rel_err(g_, w_) <= TOL_L, (trial, nX, nE, nA, nT)
+        # Planck family (fp64 entry points)
+        Tm = rng.uniform(180.0, 340.0, (int(rng.integers(1, 5)), int(rng.integers(1, 4))))
+        L = rt.planckian(X, Tm)
+        assert rel_err(L, ref.planckian(X, Tm)) <= 1e-12
+        assert rel_err(rt.brightnessTemperature(X, L), ref.brightnessTemperature(X, L)) <= 1e-10
+        assert rel_err(rt.BT2L(X, np.broadcast_to(Tm[None], (nX,) + Tm.shape)), ref.BT2L(X, np.broadcast_to(Tm[None], (nX,) + Tm.shape))) <= 1e-12
+    for trial in range(6):
+        n = int(rng.integers(3000, 30000))
+        lo = float(rng.uniform(700.0, 800.0))
+        hi = float(rng.uniform(1150.0, 1400.0))
+        X = np.linspace(lo, hi, n)
+        nS = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
+        Y = rng.uniform(0.0, 10.0, (n, nS)) * (1.0 + 0.5 * np.sin(0.05 * X))[:, None]
+        Yin = Y[:, 0] if nS == 1 and trial % 2 else Y
+        xo, yo = rt.ILS_MAKO(X, Yin, fwhm_sf=float(rng.uniform(0.7, 1.6)) if trial % 3 else 1.0)
+        xr, yr = ref.ILS_MAKO(X, Yin, fwhm_sf=1.0) if not trial % 3 else (None, None)
+        if xr is not None:
+            assert np.array_equal(xo, xr) and yo.shape == yr.shape and rel_err(yo, yr) <= TOL_L, (trial, n, nS)
+        xg, yg = ilsg.ILS_MAKO(X, Yin)
+        xgr, ygr = ref.ILS_MAKO_gauss(X, Yin)
+        assert np.array_equal(xg, xgr)
+        # the Gaussian band list is not clipped to the grid (ILS_MAKO.py:13-19): a band centred outside is the average
+        # of the edge region under the far tail until the reference's fp64 weights all underflow (0/0 = NaN). Compare
+        # everything except the bands whose largest weight is a denormal (exponent between -700 and -745).
+        sig = np.abs(np.gradient(xgr))
+        d0 = np.maximum(np.maximum(X[0] - xgr, xgr - X[-1]), 0.0)
+        expo = 0.5 * (d0 / sig) ** 2 + np.log(sig * np.sqrt(2.0 * np.pi))
+        live, dead = expo < 700.0, expo > 745.5
+        yg2, ygr2 = yg.reshape(xgr.size, -1), ygr.reshape(xgr.size, -1)
+        assert np.isfinite(ygr2[live]).all() and np.isfinite(yg2[live]).all(), (trial, n, nS)
+        assert rel_err(yg2[live], ygr2[live]) <= TOL_L, (trial, n, nS)
+        assert np.isnan(ygr2[dead]).all() and np.isnan(yg2[dead]).all(), (trial, n, nS)
