@@ -771,3 +771,52 @@ def test_streaming_stages_random_shapes_vs_oracle(rt):
         assert np.isfinite(ygr2[live]).all() and np.isfinite(yg2[live]).all(), (trial, n, nS)
         assert rel_err(yg2[live], ygr2[live]) <= TOL_L, (trial, n, nS)
         assert np.isnan(ygr2[dead]).all() and np.isnan(yg2[dead]).all(), (trial, n, nS)
+
+
+def test_fused_sensor_paths_random_configurations_vs_oracle(rt):
+    """sensor.band_radiance / band_radiance_fused / hsi_cube against np.interp + the oracle's at-sensor radiance + ILS
+    for random monochromatic axes (clipping the MAKO band list at either end), random knot sets (sparse, dense, not
+    covering the axis), odd emissivity counts, resFactor and surface temperatures."""
+    import torch
+    from radtxfr_amd import engine, sensor
+
+    rng = np.random.default_rng(20261014)
+    dev = torch.device("cuda")
+    f32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32), device=dev)
+    for trial in range(6):
+        lo = float(rng.uniform(740.0, 900.0))
+        hi = float(rng.uniform(1100.0, 1340.0))
+        n = int(rng.integers(20000, 60000))
+        grid = engine.Grid(lo, hi, n)
+        X = grid.axis()
+        nk = int(rng.choice([2, 7, 60, 700]))
+        Xk = np.sort(rng.uniform(lo - 30.0, hi + 30.0, nk)) if trial % 2 else np.sort(rng.uniform(lo + 40.0, hi - 40.0, nk))
+        nE = int(rng.choice([1, 3, 5, 8]))
+        em = rng.uniform(0.05, 1.0, (nk, nE))
+        tau = 0.5 + 0.45 * np.sin(X / rng.uniform(5, 40))
+        La = 2.0 + np.cos(X / rng.uniform(5, 40))
+        Ld = 4.0 + 2.0 * np.sin(X / rng.uniform(3, 20))
+        Ts = float(rng.uniform(260.0, 330.0))
+        rf = None if trial % 3 else 2
+        em_hi = np.stack([np.interp(X, Xk, em[:, k]) for k in range(nE)], axis=1)
+        L_ref = ref.compute_LWIR_apparent_radiance(X, em_hi, np.array([Ts]), tau[:, None], La[:, None], Ld[:, None])[:, :, 0]
+        xr, Lb_ref = ref.ILS_MAKO(X, L_ref, resFactor=rf)
+        tag = (trial, lo, hi, n, nk, nE, Ts, rf)
+        xo, Lb = sensor.band_radiance(grid, f32(tau), f32(La), f32(Ld), Xk, f32(em), Ts, resFactor=rf)
+        assert np.array_equal(xo, xr) and rel_err(Lb.cpu().numpy(), Lb_ref) <= TOL_L, ("unfused",) + tag
+        xf, Lf = sensor.band_radiance_fused(grid, f32(tau), f32(La), f32(Ld), Xk, f32(em), Ts, resFactor=rf)
+        assert np.array_equal(xf, xr) and rel_err(Lf.cpu().numpy(), Lb_ref) <= TOL_L, ("fused",) + tag
+        # pixel cube: mixtures of the nE columns with per-pixel temperatures
+        n_pix = int(rng.integers(1, 70))
+        n_mix = int(rng.integers(1, min(nE, 3) + 1))
+        kidx = rng.integers(0, nE, (n_pix, n_mix)).astype(np.int32)
+        frac = rng.uniform(0.0, 1.0, (n_pix, n_mix))
+        frac = frac / frac.sum(1, keepdims=True)
+        Tp = rng.uniform(270.0, 330.0, n_pix)
+        xo, cube = sensor.hsi_cube(grid, f32(tau), f32(La), f32(Ld), Xk, f32(em), torch.as_tensor(kidx, device=dev), f32(frac),
+                                   torch.as_tensor(Tp, device=dev), resFactor=rf)
+        em_p = np.einsum("pm,xpm->xp", frac, em_hi[:, kidx])
+        L = tau[:, None] * (em_p * ref.planckian(X, Tp) + (1 - em_p) * Ld[:, None]) + La[:, None]
+        xr2, Lr = ref.ILS_MAKO(X, L, resFactor=rf)
+        assert np.array_equal(xo, xr2) and cube.shape == Lr.reshape(xr2.size, -1).shape, ("cube",) + tag
+        assert rel_err(cube.cpu().numpy(), Lr.reshape(xr2.size, -1)) <= TOL_L, ("cube",) + tag
