@@ -399,6 +399,14 @@ def reduce_resolution(Y, x0, h, n, dX, N=4, window="hanning", x_out=None):
         n_pts = int(np.ceil(v - 1e-9 * max(1.0, abs(v)))) + 1  # see the shim's docstring: rounding-proof ceil
         x_out = np.linspace(xa, xb, n_pts)
     x_out = np.ascontiguousarray(x_out, dtype=np.float64)
+    # The reflection padding of smooth() distorts the first and last ceil(window/2) smoothed samples -- of Y and of the
+    # knot axis X_ itself, which is then no longer uniform there. The reference's spline feels those knots with weight
+    # 0.268^distance; the uniform-knot evaluation here is only offered where that is below 1e-11.
+    margin = (sm_factor + 1) // 2 + 20
+    if x_out.size and (x_out.min() < x0 + margin * h or x_out.max() > x0 + (n - 1 - margin) * h):
+        raise NotImplementedError(
+            f"reduceResolution: output points within {margin} samples of an end of the input axis are not supported "
+            f"(window {sm_factor}: the default X_out needs a window of at least 40 samples)")
     taps, c = window_taps(sm_factor, window, symmetric=True)
     Ysm = fir_reflect(Y, taps, c)
     out = cubic_resample(Ysm, x0, h, torch.as_tensor(x_out, device=Y.device))

@@ -346,7 +346,8 @@ def reduceResolution(X, Y, dX, N=4, window="hanning", X_out=None):
     scipy's cubic interp1d through all smoothed samples. Here: one fp64 FIR kernel and one cardinal-spline kernel.
     Conscious divergences: (1) nPts = ceil(N*span/dX)+1 is evaluated with a 1e-9 guard, because N*span/dX is normally
     an exact integer and the reference's value flips between two counts with the rounding of its convolution;
-    (2) X_out must stay 26 samples inside the input axis (the default X_out does for windows of >= 26 samples): the not-a-knot end conditions and
+    (2) X_out must stay ceil(window/2) + 20 samples inside the input axis (the default X_out does for windows of
+    >= 40 samples; the reference's main caller uses 500), else NotImplementedError: the not-a-knot end conditions and
     the extrapolation of interp1d are not reproduced; (3) np.int (:1329,1336) is int."""
     Xh, h = _uniform_axis(X, "reduceResolution")
     engine.require_gpu()

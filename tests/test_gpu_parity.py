@@ -489,8 +489,8 @@ def test_smooth_and_reduce_resolution_vs_golden_g9(rt, golden):
     assert Xo8.shape == g["Xo8"].shape and rel_err(Yo8, g["Yo8"]) < 1e-10
     # the reference's early returns
     assert rt.smooth(g["Y1"][:5], 11) is not None and rt.smooth(g["Y1"][:5], 11).shape == (5,)
-    with pytest.raises(Exception):
-        rt.reduceResolution(g["Xf"], g["Y1"], 0.05, X_out=g["Xf"][:10])  # within 26 samples of the end
+    with pytest.raises(NotImplementedError):
+        rt.reduceResolution(g["Xf"], g["Y1"], 0.05, X_out=g["Xf"][:10])  # inside the distorted end region
 
 
 @pytest.mark.gpu
@@ -820,3 +820,62 @@ def test_fused_sensor_paths_random_configurations_vs_oracle(rt):
         xr2, Lr = ref.ILS_MAKO(X, L, resFactor=rf)
         assert np.array_equal(xo, xr2) and cube.shape == Lr.reshape(xr2.size, -1).shape, ("cube",) + tag
         assert rel_err(cube.cpu().numpy(), Lr.reshape(xr2.size, -1)) <= TOL_L, ("cube",) + tag
+
+
+def test_compute_tud_random_atmospheres_vs_oracle(rt):
+    """The drop-in rt.compute_TUD end to end (prologue, line-sum, TUD) against the oracle for random atmospheres: layer
+    counts 3..60 of the standard atmosphere (up to 120 km: Doppler-dominated lines, the fp64 pass), perturbed
+    temperatures, mixing ratios scaled from opaque to thin, sensor altitudes inside the column, slant paths, grid steps."""
+    rng = np.random.default_rng(20261015)
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    A = synthetic.load_standard_atmosphere()
+    for trial in range(5):
+        nL = int(rng.integers(3, 61))
+        a = {"Zs": A[:nL, 1].copy(), "Ts": A[:nL, 5] + rng.uniform(-15.0, 15.0, nL), "Ps": A[:nL, 4].copy(), "PLs": A[:nL, 3].copy(),
+             "MFs_VAL": A[:nL, 6:8] * 1e6 * 10.0 ** rng.uniform(-4.5, 0.0), "MFs_ID": np.array([1, 2])}
+        dv = float(rng.choice([0.0005, 0.001, 0.004]))
+        lo = float(rng.uniform(520.0, 5900.0))
+        hi = lo + dv * int(rng.integers(1500, 4000))
+        sub = synthetic.subset_table(full, lo - 12.0, hi + 12.0)
+        alts = [500] if trial % 2 == 0 else sorted(rng.uniform(a["Zs"][0], a["Zs"][-1] + 5.0, 2).tolist())
+        theta = float(rng.choice([0.0, 0.5]))
+        nA = int(rng.choice([30, 12]))
+        X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=dv, line_table=sub, Altitudes=np.asarray(alts), theta_r=theta, N_angle=nA, **a)
+        Xr, tr, ur, dr = ref.compute_TUD(sub, lo, hi, dv, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"],
+                                        Altitudes=alts, theta_r=theta, N_angle=nA)
+        tag = (trial, nL, dv, lo, hi, alts, theta, nA)
+        assert np.array_equal(X, Xr) and tau.shape == np.shape(tr) and Lu.shape == np.shape(ur), tag
+        assert np.max(np.abs(tau - tr)) <= TOL_TAU, tag
+        assert rel_err(Lu, ur) <= TOL_L and rel_err(Ld, dr) <= TOL_L, tag
+
+
+def test_reduce_resolution_random_configurations_vs_oracle(rt):
+    """rt.smooth / rt.reduceResolution against the oracle (NumPy convolution + scipy's cubic interp1d) for random axis
+    lengths, window lengths (odd and even), window kinds, N, and explicit X_out inside the supported interior."""
+    rng = np.random.default_rng(20261016)
+    for trial in range(8):
+        n = int(rng.integers(2000, 20000))
+        lo = float(rng.uniform(500.0, 3000.0))
+        h = float(10.0 ** rng.uniform(-3.5, -2.0))
+        X = lo + h * np.arange(n)
+        Y = 1.0 + 0.5 * np.sin(rng.uniform(20, 400) * X) + 0.05 * rng.standard_normal(n)
+        nC = int(rng.choice([1, 2, 5]))
+        Y2 = np.stack([Y * (k + 1) + k for k in range(nC)], axis=1)
+        wl = int(rng.integers(3, 120))
+        win = str(rng.choice(["flat", "hanning", "hamming", "bartlett", "blackman"]))
+        assert rel_err(rt.smooth(Y, wl, win), ref.smooth(Y, wl, win)) < 1e-12, (trial, n, wl, win)
+        sm = int(rng.integers(40, min(300, n // 6)))
+        dX = sm * h
+        N = int(rng.choice([2, 4, 8]))
+        Xo_ref, Yo_ref = ref.reduceResolution(X, Y2 if nC > 1 else Y, dX, N=N, window=win)
+        Xo, Yo = rt.reduceResolution(X, Y2 if nC > 1 else Y, dX, N=N, window=win)
+        tag = (trial, n, h, sm, N, win, nC)
+        if Xo.shape != Xo_ref.shape:  # the reference's own ceil() rounding flip (DESIGN 4.6): compare on its axis instead
+            Yo = rt.reduceResolution(X, Y2 if nC > 1 else Y, dX, N=N, window=win, X_out=Xo_ref)
+        else:
+            assert np.allclose(Xo, Xo_ref, rtol=1e-12, atol=0), tag
+        assert Yo.shape == Yo_ref.shape and rel_err(Yo, Yo_ref) < 1e-9, tag
+        Xq = np.sort(rng.uniform(X[sm // 2 + 24], X[-sm // 2 - 26], 57))
+        assert rel_err(rt.reduceResolution(X, Y, dX, N=N, window=win, X_out=Xq), ref.reduceResolution(X, Y, dX, N=N, window=win, X_out=Xq)) < 1e-9, tag
+    with pytest.raises(NotImplementedError):  # a short window: the distorted end samples are too close to the first output point
+        rt.reduceResolution(X, Y, 12 * h)
