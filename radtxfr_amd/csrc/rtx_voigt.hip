@@ -1,4 +1,7 @@
-// Voigt line-sum: gather formulation of the reference's per-line scatter-add
+// Voigt line-sum: gather formulation of the reference's per-line scatter-add. This file holds the dispatcher
+// (rtx_voigt_sum), the per-tile line ranges, and the register-accumulator kernel that was the first formulation; the
+// default is now the nodal kernel of rtx_voigt_scatter.hip. This one stays selectable (RADTXFR_VOIGT_KERNEL=gather) as
+// the formulation that is bit-identical across wavenumber shards, and as a cross-check (tests run all three).
 // (misc/hapi.py:11050, 11135-11138; PROFILE_VOIGT :10131 -> pcqsdhc PART1 :9900-9915 ->
 // hum1_wei :9833-9844).
 //

@@ -1,5 +1,6 @@
-// Voigt line-sum, "scatter into per-wave LDS tiles" formulation (the default; rtx_voigt.hip holds the
-// register-accumulator gather kernel it replaced and shares the record layout and the Weideman code).
+// Voigt line-sum, "scatter into per-wave LDS tiles" formulations: the default nodal kernel and the point-by-point
+// scatter kernel it grew out of (rtx_voigt.hip holds the dispatcher and the earlier register-accumulator gather
+// kernel; all three share the record layout and the Weideman code).
 //
 // A workgroup owns a tile of SC_TILE consecutive grid points of one layer; EACH LINE IS TAKEN BY EXACTLY ONE
 // WAVE, which accumulates the line into ITS OWN copy of the tile in LDS (plain ds_read/add/ds_write: no other
