@@ -82,6 +82,27 @@ def make_g10(hapi):
          gl_n=30001, gd_lo=1000.0, gd_hi=1003.0, gd_n=30001, **out)
 
 
+def make_g11(hapi):
+    """G11: absorptionCoefficient_SDVoigt with speed-dependence columns."""
+    tbl = dict(synthetic.synth_line_table(synthetic.SEED_C2, 400, 895.0, 917.0))
+    rng = np.random.default_rng(20261017)
+    tbl["SD_air"] = rng.uniform(0.05, 0.2, 400)
+    tbl["SD_self"] = rng.uniform(0.0, 0.1, 400)
+    tbl["SD_air"][::7] = 0.0  # some lines without speed dependence (PART1 for those)
+    tbl["SD_self"][::7] = 0.0
+    inject_table(hapi, "g11", tbl)
+    g = np.linspace(900.0, 912.0, 6001)
+    out = {}
+    for tag, kw in (("a", dict(Environment={"T": 250.0, "p": 0.3})),
+                    ("b", dict(Environment={"T": 296.0, "p": 1.0}, Diluent={"air": 0.6, "self": 0.4})),
+                    ("c", dict(Environment={"T": 220.0, "p": 0.01})),
+                    ("d", dict(Environment={"T": 300.0, "p": 0.8}, HITRAN_units=False, OmegaWing=0.5, OmegaWingHW=20.0,
+                               Components=[(1, 1), (2, 1, 0.5)]))):
+        _, out["xs_" + tag] = quiet(hapi.absorptionCoefficient_SDVoigt, SourceTables="g11", OmegaGrid=g, **kw)
+    save("g11_sdvoigt.npz", seed=synthetic.SEED_C2, n_lines=400, nu_lo=895.0, nu_hi=917.0, g_lo=900.0, g_hi=912.0, g_n=6001,
+         SD_air=tbl["SD_air"], SD_self=tbl["SD_self"], **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rt, hapi, ils_gauss = load()
@@ -231,6 +252,7 @@ def main():
 
     make_g9(rt)
     make_g10(hapi)
+    make_g11(hapi)
 
 
 if __name__ == "__main__":
@@ -240,5 +262,8 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["g10"]:
         os.makedirs(OUT, exist_ok=True)
         make_g10(load()[1])
+    elif sys.argv[1:] == ["g11"]:
+        os.makedirs(OUT, exist_ok=True)
+        make_g11(load()[1])
     else:
         main()

@@ -183,3 +183,26 @@ def test_g10_lorentz_doppler(golden):
         close(xs, g["dop_" + tag], rtol=1e-10, atol=1e-40)
     _, xs = ref.absorptionCoefficient_Doppler(tbl, LineShift=False, T=296.0, p=1.0, OmegaGrid=gd, HITRAN_units=False, OmegaWing=0.05)
     close(xs, g["dop_noshift"], rtol=1e-10, atol=1e-30)
+
+
+def _g11_table(g):
+    tbl = dict(synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"])))
+    tbl["SD_air"], tbl["SD_self"] = g["SD_air"], g["SD_self"]
+    return tbl, np.linspace(float(g["g_lo"]), float(g["g_hi"]), int(g["g_n"]))
+
+
+def test_g11_sdvoigt(golden):
+    """Oracle restatement of PROFILE_SDVOIGT / pcqsdhc (anuVC = eta = 0) against the reference run."""
+    g = golden("g11_sdvoigt.npz")
+    tbl, grid = _g11_table(g)
+    _, xs = ref.absorptionCoefficient_SDVoigt(tbl, T=250.0, p=0.3, OmegaGrid=grid)
+    close(xs, g["xs_a"], rtol=1e-11, atol=1e-40)
+    _, xs = ref.absorptionCoefficient_SDVoigt(tbl, T=296.0, p=1.0, OmegaGrid=grid, Diluent={"air": 0.6, "self": 0.4})
+    close(xs, g["xs_b"], rtol=1e-11, atol=1e-40)
+    _, xs = ref.absorptionCoefficient_SDVoigt(tbl, T=220.0, p=0.01, OmegaGrid=grid)
+    close(xs, g["xs_c"], rtol=1e-11, atol=1e-40)
+    _, xs = ref.absorptionCoefficient_SDVoigt(tbl, T=300.0, p=0.8, OmegaGrid=grid, HITRAN_units=False, OmegaWing=0.5, OmegaWingHW=20.0,
+                                              Components=[(1, 1), (2, 1, 0.5)])
+    close(xs, g["xs_d"], rtol=1e-11, atol=1e-30)
+    _, xv = ref.absorptionCoefficient_Voigt(tbl, T=250.0, p=0.3, OmegaGrid=grid)
+    assert np.max(np.abs(xv - g["xs_a"])) / np.max(xv) > 5e-3  # the speed dependence is not a rounding-level effect here
