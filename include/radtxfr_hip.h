@@ -63,6 +63,9 @@ int rtx_lines_create(int64_t n_lines, int n_species, const double* nu_h, const d
                      const int32_t* species_h, rtx_lines** out);
 int rtx_lines_free(rtx_lines* lines);
 int64_t rtx_lines_count(const rtx_lines* lines);
+/* Optional speed-dependence columns SD_air / SD_self (misc/hapi.py:10884-10887), in the order of the rows given to
+ * rtx_lines_create; either may be NULL (= 0). Only rtx_line_prep_profile(RTX_PROFILE_SDVOIGT) reads them. */
+int rtx_lines_set_sd(rtx_lines* lines, const double* sd_air_h, const double* sd_self_h);
 
 /* ------------------------------------------------------------------------------------------
  * Per-(line, layer) prologue, fp64. Replaces the per-line environment block of
@@ -101,6 +104,7 @@ int rtx_line_prep(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, 
 #define RTX_PROFILE_VOIGT 0
 #define RTX_PROFILE_LORENTZ 1
 #define RTX_PROFILE_DOPPLER 2
+#define RTX_PROFILE_SDVOIGT 3 /* records for rtx_sdvoigt_sum (below); windows as for Voigt */
 int rtx_line_prep_profile(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, int n_layers,
                           const double* T_h, const double* p_atm_h, const double* qratio_h,
                           const double* weight_h, const double* mass_h, double dil_air,
@@ -223,6 +227,17 @@ int rtx_pixel_cube(int nB, int Q, const double* centre, const double* sigma, dou
                    const float* s_node_h, const float* N, const float* C, const float* ALd,
                    const float* AB, int nEnd, int64_t nPix, int nMix, const int32_t* kidx,
                    const float* frac, const double* Tpix, float* cube, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Speed-dependent Voigt line-sum. Replaces the per-line PROFILE_SDVOIGT + scatter-add of
+ * absorptionCoefficient_SDVoigt, misc/hapi.py:10897-10900 (PROFILE_SDVOIGT :10117 -> pcqsdhc :9850-10024 with
+ * anuVC = eta = 0: PART1 for lines without speed dependence, PART2/3/4 otherwise; CPF = hum1_wei :9833, cpf3 :9645),
+ * after rtx_line_prep_profile(..., RTX_PROFILE_SDVOIGT, ...). Evaluated in fp64 (the profile is a difference of two
+ * complex probability functions), one thread per grid point; this is the cross-section generator's path
+ * (misc/RT_gen_AbsXS_files.py:90), not the TUD hot path.
+ *   out_f32[n_layers][ld] (may be NULL)  (float)(sum * scale);  out_f64[n_layers][ld] (may be NULL)  sum */
+int rtx_sdvoigt_sum(const rtx_prep* prep, const rtx_grid* grid, int n_layers, float* out_f32,
+                    double* out_f64, int64_t ld, void* stream);
 
 /* ---- post-processing of TUD products: smooth / reduceResolution ---------------------
  * Replaces radiative_transfer.py:1266-1324 (smooth: reflect-padded window convolution) and :1327-1350

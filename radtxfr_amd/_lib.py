@@ -35,6 +35,8 @@ PROTOTYPES = {
     "rtx_line_prep": (_i32, [_vp, _vp, _gp, _i32, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _vp]),
     "rtx_line_prep_profile": (_i32, [_vp, _vp, _gp, _i32, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _vp]),
     "rtx_voigt_sum": (_i32, [_vp, _gp, _i32, _vp, _vp, _i64, _vp]),
+    "rtx_sdvoigt_sum": (_i32, [_vp, _gp, _i32, _vp, _vp, _i64, _vp]),
+    "rtx_lines_set_sd": (_i32, [_vp, _vp, _vp]),
     "rtx_voigt_tile_points": (_i32, []),
     "rtx_planck": (_i32, [_gp, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "rtx_tud": (_i32, [_vp, _i64, _gp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -48,8 +48,8 @@ def AFIT_XS_read(File):
 def cross_section_grid(SourceTables, T, P_atm, X, WavenumberWingHW=50.0, WavenumberWing=0.0, IntensityThreshold=0.0,
                        GammaL="gamma_air", Components=None):
     """HITRAN-unit Voigt cross sections [cm^2/molecule] of one table for every (T, p) pair of the grids: the body of the
-    reference's double loop (RT_gen_AbsXS_files.py:88-90, absorptionCoefficient_SDVoigt on tables without SD columns =
-    Voigt) as one batched launch per 128 states. X must be uniform. Returns xs[nT][nP][nX] float64 (host)."""
+    reference's double loop (RT_gen_AbsXS_files.py:88-90: absorptionCoefficient_SDVoigt, i.e. the Voigt line-sum for tables
+    without speed-dependence columns and rtx_sdvoigt_sum for tables with them) as one batched launch per 128 states. X must be uniform. Returns xs[nT][nP][nX] float64 (host)."""
     T = np.atleast_1d(np.asarray(T, dtype=np.float64))
     P = np.atleast_1d(np.asarray(P_atm, dtype=np.float64))
     X = np.asarray(X, dtype=np.float64)
@@ -76,7 +76,7 @@ def cross_section_grid(SourceTables, T, P_atm, X, WavenumberWingHW=50.0, Wavenum
         if tbl.n:
             engine.voigt_sum(tbl, grid, Tk, pk, np.tile(w[:, None], (1, len(chunk))), out_f64=dev, dil_air=dil.get("air", 0.0),
                              dil_self=dil.get("self", 0.0), omega_wing=WavenumberWing, omega_wing_hw=WavenumberWingHW,
-                             intensity_threshold=IntensityThreshold, scale=scale)
+                             intensity_threshold=IntensityThreshold, scale=scale, profile=3 if tbl.has_sd else 0)
             out[s0:s0 + len(chunk)] = dev.cpu().numpy()
         else:
             out[s0:s0 + len(chunk)] = 0.0

@@ -100,10 +100,17 @@ struct __attribute__((aligned(16))) LineRec64 {
   double A;
 };
 
+// fp64 record of the speed-dependent Voigt sum (rtx_sdvoigt_sum): PROFILE_SDVOIGT's arguments (misc/hapi.py:10897)
+// and the line's weight * S(T).
+struct __attribute__((aligned(16))) LineRecSD {
+  double nu, cte, Gam0, Shift0, Gam2, WS;
+};
+
 struct rtx_lines {
   long long n;
   int n_species;
   double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
+  double *sd_air, *sd_self;  // optional speed-dependence columns (rtx_lines_set_sd), NULL = 0
   int* species;
 };
 
@@ -117,6 +124,7 @@ struct rtx_prep {
   int* maxhw;          // [max_layers] max window half-width in grid points (+margin)
   int2* ranges;        // [max_layers][max_tiles] candidate line range per line-sum tile
   int* smally;         // [max_layers] set when a line of that layer has a Weideman band with y < 1
+  LineRecSD* recsd;    // [max_layers][n_lines], allocated by the first speed-dependent prologue
   long long max_tiles;
   double* env;         // device copy of T,p,qratio,weight,mass (packed)
   size_t env_cap;

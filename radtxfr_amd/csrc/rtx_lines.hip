@@ -54,7 +54,8 @@ static int upload(double** dst, const double* src_h, long long n, bool zero_if_n
 
 extern "C" int rtx_lines_free(rtx_lines* L) {
   if (!L) return 0;
-  double* p[] = {L->nu, L->sw, L->elower, L->gamma_air, L->gamma_self, L->n_air, L->n_self, L->delta_air, L->deltap_air, L->delta_self};
+  double* p[] = {L->nu, L->sw, L->elower, L->gamma_air, L->gamma_self, L->n_air, L->n_self, L->delta_air, L->deltap_air, L->delta_self,
+                 L->sd_air, L->sd_self};
   for (double* q : p)
     if (q) (void)hipFree(q);
   if (L->species) (void)hipFree(L->species);
@@ -108,6 +109,19 @@ extern "C" int rtx_lines_create(int64_t n, int n_species, const double* nu_h, co
 }
 extern "C" int64_t rtx_lines_count(const rtx_lines* L) { return L ? L->n : -1; }
 
+extern "C" int rtx_lines_set_sd(rtx_lines* L, const double* sd_air_h, const double* sd_self_h) {
+  if (!L) RTX_FAIL("lines is NULL");
+  const double* src[2] = {sd_air_h, sd_self_h};
+  double** dst[2] = {&L->sd_air, &L->sd_self};
+  for (int c = 0; c < 2; ++c) {
+    if (*dst[c]) { (void)hipFree(*dst[c]); *dst[c] = nullptr; }
+    if (!src[c] || L->n == 0) continue;
+    RTX_HIP(hipMalloc((void**)dst[c], (size_t)L->n * sizeof(double)));
+    RTX_HIP(hipMemcpy(*dst[c], src[c], (size_t)L->n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
 // ---- prep object -------------------------------------------------------------------------------------
 extern "C" int rtx_prep_free(rtx_prep* P) {
   if (!P) return 0;
@@ -118,6 +132,7 @@ extern "C" int rtx_prep_free(rtx_prep* P) {
   if (P->env) (void)hipFree(P->env);
   if (P->ranges) (void)hipFree(P->ranges);
   if (P->smally) (void)hipFree(P->smally);
+  if (P->recsd) (void)hipFree(P->recsd);
   delete P;
   return 0;
 }
@@ -164,6 +179,8 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
 
 struct PrepArgs {
   const double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
+  const double *sd_air, *sd_self;
+  LineRecSD* recsd;
   const int* species;
   long long n_lines;
   int n_layers, n_species;
@@ -298,6 +315,15 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     const size_t o = (size_t)k * (size_t)a.n_lines + (size_t)l;
     a.rec[o] = r;
     a.rec64[o] = r64;
+    if (a.profile == RTX_PROFILE_SDVOIGT) {
+      // Gamma2 = sum_species abun * SD_species * p/pref * gamma_species(Tref) (misc/hapi.py:10884-10890); Shift2 = 0
+      double Gam2 = 0.0;
+      if (a.dil_air != 0.0 && a.sd_air) Gam2 += a.dil_air * (a.sd_air[l] * p) * a.gamma_air[l];
+      if (a.dil_self != 0.0 && a.sd_self) Gam2 += a.dil_self * (a.sd_self[l] * p) * a.gamma_self[l];
+      LineRecSD q;
+      q.nu = nu; q.cte = cte; q.Gam0 = Gamma0; q.Shift0 = Shift0; q.Gam2 = Gam2; q.WS = dropped ? 0.0 : w * S;
+      a.recsd[o] = q;
+    }
     if (k == 0) {
       long long gic = llrint((nu - g.xmin) / g.step);
       if (gic < -M) gic = -M;
@@ -326,7 +352,11 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
                              double dil_air, double dil_self, double omega_wing, double omega_wing_hw,
                              double intensity_threshold, double scale, int profile, void* stream) {
   if (!P || !L) RTX_FAIL("prep/lines is NULL");
-  if (profile < RTX_PROFILE_VOIGT || profile > RTX_PROFILE_DOPPLER) RTX_FAIL("profile=%d", profile);
+  if (profile < RTX_PROFILE_VOIGT || profile > RTX_PROFILE_SDVOIGT) RTX_FAIL("profile=%d", profile);
+  if (profile == RTX_PROFILE_SDVOIGT && !P->recsd) {
+    const size_t nrec = (size_t)(P->n_lines > 0 ? P->n_lines : 1) * (size_t)P->max_layers;
+    RTX_HIP(hipMalloc((void**)&P->recsd, nrec * sizeof(LineRecSD)));
+  }
   if (rtx_check_grid(grid)) return 1;
   if (P->n_lines != L->n) RTX_FAIL("prep object was created for %lld lines, table has %lld", P->n_lines, L->n);
   if (n_layers < 1 || n_layers > P->max_layers) RTX_FAIL("n_layers=%d outside [1,%d]", n_layers, P->max_layers);
@@ -354,6 +384,7 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
   a.nu = L->nu; a.sw = L->sw; a.elower = L->elower; a.gamma_air = L->gamma_air; a.gamma_self = L->gamma_self;
   a.n_air = L->n_air; a.n_self = L->n_self; a.delta_air = L->delta_air; a.deltap_air = L->deltap_air;
   a.delta_self = L->delta_self; a.species = L->species;
+  a.sd_air = L->sd_air; a.sd_self = L->sd_self; a.recsd = P->recsd;
   a.n_lines = L->n; a.n_layers = n_layers; a.n_species = ns;
   a.T = d; a.p = d + nT; a.qratio = d + 2 * nT; a.weight = d + 2 * nT + nQ; a.mass = d + 2 * nT + 2 * nQ;
   a.dil_air = dil_air; a.dil_self = dil_self; a.omega_wing = omega_wing; a.omega_wing_hw = omega_wing_hw;

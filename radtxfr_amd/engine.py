@@ -125,6 +125,16 @@ class LineTable:
             self.n, len(self.species), ptr("nu"), ptr("sw"), ptr("elower"), ptr("gamma_air"), ptr("gamma_self"),
             ptr("n_air"), ptr("n_self"), ptr("delta_air"), ptr("deltap_air"), ptr("delta_self"),
             sp.ctypes.data_as(C.c_void_p), C.byref(self._h)))
+        # optional speed-dependence columns (absorptionCoefficient_SDVoigt, misc/hapi.py:10884-10887)
+        self.has_sd = False
+        sd = {}
+        for k in ("SD_air", "SD_self"):
+            if k in columns:
+                sd[k] = np.ascontiguousarray(np.asarray(columns[k], dtype=np.float64)[order])
+                self.has_sd = self.has_sd or bool(np.any(sd[k] != 0.0))
+        if self.has_sd:
+            sp_ = lambda k: sd[k].ctypes.data_as(C.c_void_p) if k in sd else C.c_void_p(0)
+            _lib.check(lib.rtx_lines_set_sd(self._h, sp_("SD_air"), sp_("SD_self")))
         self._plans = {}
 
     def plan(self, n_layers, n_points):
@@ -194,7 +204,8 @@ def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air
               omega_wing_hw=50.0, intensity_threshold=0.0, scale=1.0, partitionFunction=None, qratio=None, mass=None,
               profile=0):
     """Prologue + line-sum for n_layers homogeneous states on `grid` (rtx_line_prep_profile + rtx_voigt_sum);
-    profile 0 Voigt, 1 Lorentz, 2 Doppler (include/radtxfr_hip.h).
+    profile 0 Voigt, 1 Lorentz, 2 Doppler, 3 speed-dependent Voigt (include/radtxfr_hip.h; 3 needs SD columns in `lines`
+    and runs rtx_sdvoigt_sum).
     weight[nS][nL] multiplies S(T) per species and layer. Outputs are [nL][grid.n] device tensors."""
     lib = _lib.load()
     T = np.atleast_1d(np.asarray(T, dtype=np.float64))
@@ -216,7 +227,10 @@ def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air
     for o, dt in ((out_f32, torch.float32), (out_f64, torch.float64)):
         if o is not None:
             assert o.dtype == dt and o.is_cuda and o.is_contiguous() and o.shape == (nL, ld), (o.dtype, o.shape)
-    _lib.check(lib.rtx_voigt_sum(plan._h, grid.byref(), nL, _ptr(out_f32), _ptr(out_f64), ld, st))
+    if int(profile) == 3:  # speed-dependent Voigt: its own fp64 line-sum
+        _lib.check(lib.rtx_sdvoigt_sum(plan._h, grid.byref(), nL, _ptr(out_f32), _ptr(out_f64), ld, st))
+    else:
+        _lib.check(lib.rtx_voigt_sum(plan._h, grid.byref(), nL, _ptr(out_f32), _ptr(out_f64), ld, st))
     return out_f32, out_f64
 
 

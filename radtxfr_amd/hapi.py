@@ -56,7 +56,7 @@ def _device_table(names):
         for k, v in d.items():
             cols.setdefault(k, []).append(np.asarray(v)[:nrow])
     use = [k for k in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air",
-                       "n_self", "deltap_air", "delta_self") if k in keys]
+                       "n_self", "deltap_air", "delta_self", "SD_air", "SD_self") if k in keys]
     for req in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "n_air", "delta_air"):
         if req not in use:
             raise Exception("table(s) %s lack the column %s" % (names, req))
@@ -243,22 +243,21 @@ def absorptionCoefficient_SDVoigt(Components=None, SourceTables=None, partitionF
                                   GammaL="gamma_air", HITRAN_units=True, LineShift=True, File=None, Format=None,
                                   OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
                                   WavenumberWingHW=None, WavenumberGrid=None, Diluent={}, EnvDependences=None):
-    """Speed-dependent Voigt, signature of misc/hapi.py:10657-10904 -- for tables WITHOUT speed-dependence columns.
+    """Speed-dependent Voigt, signature of misc/hapi.py:10657-10904.
 
-    The reference reads SD_air / SD_self (:10884-10890); a table that lacks them (the 160-character HITRAN .par
-    format has none) gives Gamma2 = Shift2 = 0, for which pcqsdhc takes its PART1 branch (:9908-9915), i.e. the Voigt
-    profile: in the reference itself the two functions then agree to 2e-12 (checked in the build container). This
-    shim evaluates that case through the Voigt path; non-zero SD columns raise NotImplementedError (pcqsdhc PART2-4,
-    the quadratic speed dependence, is not implemented on the GPU)."""
+    Tables without speed-dependence columns (the 160-character HITRAN .par format has none) give Gamma2 = 0, for which
+    pcqsdhc takes its PART1 branch (:9908-9915), i.e. the Voigt profile: those go through the fp32 Voigt line-sum.
+    Tables with non-zero SD_air / SD_self (:10884-10890) go through rtx_sdvoigt_sum: pcqsdhc PART2-4 in fp64, one thread
+    per grid point (the path of the reference's cross-section generator, misc/RT_gen_AbsXS_files.py:90)."""
+    sd = False
     for name in listOfTuples(SourceTables):
         if name is None or name not in LOCAL_TABLE_CACHE:
             continue
         data = LOCAL_TABLE_CACHE[name]["data"]
         for col in ("SD_air", "SD_self"):
             if col in data and np.any(np.asarray(data[col], dtype=np.float64) != 0.0):
-                raise NotImplementedError("absorptionCoefficient_SDVoigt: table %r has non-zero %s (speed dependence is not "
-                                          "implemented; the Voigt limit is)" % (name, col))
-    return _absorption_coefficient(0, Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep, OmegaWing,
-                                   IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format, OmegaGrid,
-                                   WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid, Diluent,
-                                   EnvDependences)
+                sd = True
+    return _absorption_coefficient(3 if sd else 0, Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep,
+                                   OmegaWing, IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format,
+                                   OmegaGrid, WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid,
+                                   Diluent, EnvDependences)

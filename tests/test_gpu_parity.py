@@ -547,7 +547,7 @@ def test_g10_lorentz_doppler_golden(hapi, golden):
 
 def test_sdvoigt_is_the_voigt_limit_without_sd_columns(hapi, golden):
     """hapi.absorptionCoefficient_SDVoigt on a table without SD_* columns is the Voigt profile (misc/hapi.py:9908-9915):
-    same result as the Voigt shim, within tolerance of the reference's Voigt golden; non-zero SD columns are refused."""
+    same result as the Voigt shim, within tolerance of the reference's Voigt golden."""
     g = golden("g4_voigt_xsec.npz")
     grid = _g4_table(hapi, g)[20000:26000]
     env = {"T": float(g["T_l01"]), "p": float(g["p_l01"])}
@@ -555,11 +555,33 @@ def test_sdvoigt_is_the_voigt_limit_without_sd_columns(hapi, golden):
     _, xs = hapi.absorptionCoefficient_SDVoigt(SourceTables="g4", Environment=env, OmegaGrid=grid)
     assert np.array_equal(xs, xv)
     assert rel_err(xs, g["xs_l01"][20000:26000]) <= TOL_L
-    tbl = dict(synthetic.synth_line_table(7, 50, 900.0, 905.0))
-    tbl["SD_air"] = np.full(50, 0.1)
-    hapi.storage2cache_from_columns("sdv", tbl)
-    with pytest.raises(NotImplementedError):
-        hapi.absorptionCoefficient_SDVoigt(SourceTables="sdv", OmegaGrid=np.linspace(900.0, 905.0, 501))
+
+
+def test_g11_sdvoigt_golden(hapi, golden):
+    """hapi.absorptionCoefficient_SDVoigt with speed-dependence columns (rtx_sdvoigt_sum: pcqsdhc PART1-4 in fp64) against
+    the reference run; fp64 throughout, so agreement is at rounding level, not the fp32 tolerance."""
+    g = golden("g11_sdvoigt.npz")
+    tbl = dict(synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"])))
+    tbl["SD_air"], tbl["SD_self"] = g["SD_air"], g["SD_self"]
+    hapi.storage2cache_from_columns("g11", tbl)
+    grid = np.linspace(float(g["g_lo"]), float(g["g_hi"]), int(g["g_n"]))
+    cases = (("a", dict(Environment={"T": 250.0, "p": 0.3})),
+             ("b", dict(Environment={"T": 296.0, "p": 1.0}, Diluent={"air": 0.6, "self": 0.4})),
+             ("c", dict(Environment={"T": 220.0, "p": 0.01})),
+             ("d", dict(Environment={"T": 300.0, "p": 0.8}, HITRAN_units=False, OmegaWing=0.5, OmegaWingHW=20.0,
+                        Components=[(1, 1), (2, 1, 0.5)])))
+    for tag, kw in cases:
+        om, xs = hapi.absorptionCoefficient_SDVoigt(SourceTables="g11", OmegaGrid=grid, **kw)
+        assert np.array_equal(om, grid) and rel_err(xs, g["xs_" + tag]) <= 1e-9, tag
+    # a tiny speed dependence (PART2: |X| <= 3e-8 |Y|) tends to the Voigt profile
+    tiny = dict(tbl)
+    tiny["SD_air"] = np.full(int(g["n_lines"]), 1e-9)
+    tiny.pop("SD_self")
+    hapi.storage2cache_from_columns("g11t", tiny)
+    _, xt = hapi.absorptionCoefficient_SDVoigt(SourceTables="g11t", OmegaGrid=grid, Environment={"T": 250.0, "p": 0.3})
+    _, xo = ref.absorptionCoefficient_SDVoigt(tiny, T=250.0, p=0.3, OmegaGrid=grid)
+    _, xv = ref.absorptionCoefficient_Voigt(tiny, T=250.0, p=0.3, OmegaGrid=grid)
+    assert rel_err(xt, xo) <= 1e-7 and rel_err(xt, xv) <= 1e-6
 
 
 def test_afit_xs_grid_batched_states(hapi, tmp_path):
