@@ -901,3 +901,40 @@ def test_reduce_resolution_random_configurations_vs_oracle(rt):
         assert rel_err(rt.reduceResolution(X, Y, dX, N=N, window=win, X_out=Xq), ref.reduceResolution(X, Y, dX, N=N, window=win, X_out=Xq)) < 1e-9, tag
     with pytest.raises(NotImplementedError):  # a short window: the distorted end samples are too close to the first output point
         rt.reduceResolution(X, Y, 12 * h)
+
+
+def test_hapi_shim_option_combinations_vs_oracle(hapi):
+    """The option surface of hapi.absorptionCoefficient_Voigt (misc/hapi.py:10906-11141) in random combinations: explicit
+    Components with custom abundances / a filtered-out molecule, HITRAN_units on/off, GammaL air/self, Diluent mixes,
+    IntensityThreshold > 0, OmegaRange + OmegaStep instead of a grid, two SourceTables at once."""
+    rng = np.random.default_rng(20261018)
+    full = synthetic.synth_line_table(synthetic.SEED_C2, 3000, 675.0, 1425.0)
+    for trial in range(8):
+        lo = float(rng.uniform(700.0, 1350.0))
+        step = float(rng.choice([0.002, 0.005, 0.01]))
+        n = int(rng.integers(800, 5000))
+        hi = lo + step * n
+        sub = synthetic.subset_table(full, lo - 8.0, hi + 8.0)
+        nsub = len(sub["nu"])
+        # split the lines over two cached tables (the shim concatenates SourceTables)
+        cut = nsub // 3
+        t1 = {k: np.asarray(v)[:cut] for k, v in sub.items()}
+        t2 = {k: np.asarray(v)[cut:] for k, v in sub.items()}
+        hapi.storage2cache_from_columns("opt_a", t1)
+        hapi.storage2cache_from_columns("opt_b", t2)
+        Tk, p = float(rng.uniform(200.0, 320.0)), float(10.0 ** rng.uniform(-2.0, 0.05))
+        comps = [None, [(1, 1)], [(1, 1), (2, 1, 0.37)], [(2, 1, 0.011)]][trial % 4]
+        units = bool(trial % 2)
+        gl = "gamma_self" if trial % 3 == 1 else "gamma_air"
+        dil = {"air": 0.55, "self": 0.45} if trial % 3 == 2 else {}
+        thr = float(np.percentile(sub["sw"], 40)) if trial % 4 == 3 else 0.0
+        kw = dict(Components=comps, SourceTables=["opt_a", "opt_b"], Environment={"T": Tk, "p": p}, HITRAN_units=units, GammaL=gl,
+                  Diluent=dil, IntensityThreshold=thr, OmegaWingHW=25.0)
+        if trial % 2:
+            om, xs = hapi.absorptionCoefficient_Voigt(OmegaRange=[lo, hi], OmegaStep=step, **kw)
+        else:
+            om, xs = hapi.absorptionCoefficient_Voigt(OmegaGrid=np.linspace(lo, hi, n), **kw)
+        _, want = ref.absorptionCoefficient_Voigt(sub, Components=comps, T=Tk, p=p, OmegaGrid=om, OmegaWingHW=25.0, HITRAN_units=units,
+                                                  GammaL=gl, Diluent=dil or None, IntensityThreshold=thr)
+        tag = (trial, lo, step, n, Tk, p, comps, units, gl, dil, thr)
+        assert np.max(want) > 0 and rel_err(xs, want) <= TOL_L, tag
