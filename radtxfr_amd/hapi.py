@@ -261,3 +261,35 @@ def absorptionCoefficient_SDVoigt(Components=None, SourceTables=None, partitionF
                                    OmegaWing, IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format,
                                    OmegaGrid, WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid,
                                    Diluent, EnvDependences)
+
+
+_HT_PREFIXES = ("gamma_HT_", "n_HT_", "delta_HT_", "deltap_HT_", "nu_HT_", "kappa_HT_", "eta_HT_")
+
+
+def absorptionCoefficient_HT(Components=None, SourceTables=None, partitionFunction=PYTIPS, Environment=None,
+                             OmegaRange=None, OmegaStep=None, OmegaWing=None,
+                             IntensityThreshold=DefaultIntensityThreshold, OmegaWingHW=DefaultOmegaWingHW,
+                             GammaL="gamma_air", HITRAN_units=True, LineShift=True, File=None, Format=None,
+                             OmegaGrid=None, WavenumberRange=None, WavenumberStep=None, WavenumberWing=None,
+                             WavenumberWingHW=None, WavenumberGrid=None, Diluent={}, EnvDependences=None):
+    """Hartmann-Tran profile, signature of misc/hapi.py:10302-10653 -- for tables WITHOUT Hartmann-Tran columns.
+
+    The reference looks each parameter up under its HT name first (gamma_HT_0_<species>_<Tref>, n_HT_..., delta_HT_...,
+    nu_HT_..., eta_HT_..., :10505-10640) and falls back to the Voigt-style columns; a table that has none of the HT
+    names gives nuVC = eta = 0, Gamma2 from SD_<species> (:10590-10599), i.e. exactly absorptionCoefficient_SDVoigt
+    (checked against the reference in the build container: 6e-16). That case is evaluated here; non-zero HT columns raise
+    NotImplementedError (velocity-changing collisions and correlation are not implemented on the GPU)."""
+    for name in listOfTuples(SourceTables):
+        if name is None or name not in LOCAL_TABLE_CACHE:
+            continue
+        for col, vals in LOCAL_TABLE_CACHE[name]["data"].items():
+            if col.startswith(_HT_PREFIXES) and np.any(np.asarray(vals, dtype=np.float64) != 0.0):
+                raise NotImplementedError("absorptionCoefficient_HT: table %r has the Hartmann-Tran column %s; only the "
+                                          "Voigt / speed-dependent Voigt limits are implemented" % (name, col))
+    return absorptionCoefficient_SDVoigt(Components, SourceTables, partitionFunction, Environment, OmegaRange, OmegaStep, OmegaWing,
+                                         IntensityThreshold, OmegaWingHW, GammaL, HITRAN_units, LineShift, File, Format, OmegaGrid,
+                                         WavenumberRange, WavenumberStep, WavenumberWing, WavenumberWingHW, WavenumberGrid, Diluent,
+                                         EnvDependences)
+
+
+absorptionCoefficient = absorptionCoefficient_HT  # the reference's profile selector alias, misc/hapi.py:11377

@@ -573,6 +573,15 @@ def test_g11_sdvoigt_golden(hapi, golden):
     for tag, kw in cases:
         om, xs = hapi.absorptionCoefficient_SDVoigt(SourceTables="g11", OmegaGrid=grid, **kw)
         assert np.array_equal(om, grid) and rel_err(xs, g["xs_" + tag]) <= 1e-9, tag
+    # the reference's default alias absorptionCoefficient = absorptionCoefficient_HT is the same thing for tables
+    # without Hartmann-Tran columns (misc/hapi.py:10505-10640, 11377); HT columns are refused
+    _, xh = hapi.absorptionCoefficient(SourceTables="g11", OmegaGrid=grid, Environment={"T": 250.0, "p": 0.3})
+    assert rel_err(xh, g["xs_a"]) <= 1e-9
+    ht = dict(tbl)
+    ht["gamma_HT_0_air_296"] = np.full(int(g["n_lines"]), 0.05)
+    hapi.storage2cache_from_columns("g11h", ht)
+    with pytest.raises(NotImplementedError):
+        hapi.absorptionCoefficient_HT(SourceTables="g11h", OmegaGrid=grid)
     # a tiny speed dependence (PART2: |X| <= 3e-8 |Y|) tends to the Voigt profile
     tiny = dict(tbl)
     tiny["SD_air"] = np.full(int(g["n_lines"]), 1e-9)
