@@ -364,3 +364,42 @@ def reduceResolution(X, Y, dX, N=4, window="hanning", X_out=None):
     if X_out is None:
         return x_out, Y_out
     return Y_out
+
+
+# ---- small host helpers of the reference module, kept for drop-in completeness -------------------------
+def rs1D(y):
+    """(flattened copy, original shape), as radiative_transfer.py:186-203."""
+    y = np.array(y)
+    return y.flatten(), y.shape
+
+
+def rs2D(y):
+    """(2-D view with the 2nd..Nth axes flattened, original shape); a scalar or 1-D input becomes one row
+    (radiative_transfer.py:206-228)."""
+    y = np.array(y)
+    if y.ndim < 2:
+        y = np.array([y]).flatten()[np.newaxis, :]
+        return y, y.shape
+    dims = y.shape
+    return y.reshape((dims[0], int(np.prod(dims[1:])))), dims
+
+
+def rsND(y, dims):
+    """Back to the N-D shape (radiative_transfer.py:231-248)."""
+    return y.reshape(dims)
+
+
+def _no_lblrtm(name):
+    def stub(*args, **kwargs):
+        raise NotImplementedError(
+            f"{name}: the LBLRTM plumbing of the reference (TAPE5 writer, binary runner, TAPE12 reader; "
+            "radiative_transfer.py:395-789) is not part of this engine -- the LBLRTM executable and the AER line file are "
+            "git-LFS stubs in the reference checkout. compute_OD / compute_TUD take a HITRAN-format line table instead "
+            "(line_table=..., INTEGRATION.md section 2).")
+    stub.__name__ = name
+    return stub
+
+
+write_tape5 = _no_lblrtm("write_tape5")
+run_LBLRTM = _no_lblrtm("run_LBLRTM")
+read_tape12 = _no_lblrtm("read_tape12")
