@@ -293,3 +293,125 @@ def absorptionCoefficient_HT(Components=None, SourceTables=None, partitionFuncti
 
 
 absorptionCoefficient = absorptionCoefficient_HT  # the reference's profile selector alias, misc/hapi.py:11377
+
+
+# ---- a minimal table layer: what the reference's scripts do with hapi's database functions --------------------
+# (misc/RT_gen_AbsXS_files.py:12, 38-44: db_begin(folder); select(table, Conditions=..., DestinationTableName=..., File=...)).
+# hapi's full storage / SQL-like layer (misc/hapi.py:433-3216) is out of scope; these cover loading 160-character
+# .par / .data files from a folder and filtering rows by the comparison operators of hapi's condition trees.
+def db_begin(db=None):
+    """Load every `*.data` / `*.par` file of folder `db` (default 'data', as misc/hapi.py:5205-5240) into
+    LOCAL_TABLE_CACHE under the file's base name. Returns the list of table names loaded."""
+    import glob
+    import os
+
+    from . import hitran_par
+
+    folder = "data" if db is None else db
+    os.makedirs(folder, exist_ok=True)
+    names = []
+    for path in sorted(glob.glob(os.path.join(folder, "*.data")) + glob.glob(os.path.join(folder, "*.par"))):
+        name = os.path.splitext(os.path.basename(path))[0]
+        hitran_par.storage2cache(name, path)
+        names.append(name)
+    VARIABLES["BACKEND_DATABASE_NAME"] = folder
+    return names
+
+
+VARIABLES = {"BACKEND_DATABASE_NAME": "data"}
+
+
+def tableList():
+    """Names of the cached tables (misc/hapi.py:5168)."""
+    return list(LOCAL_TABLE_CACHE.keys())
+
+
+def dropTable(TableName):
+    """Forget a cached table (misc/hapi.py:2398)."""
+    LOCAL_TABLE_CACHE.pop(TableName, None)
+
+
+def getColumn(TableName, ParameterName):
+    """One column of a cached table as a list (misc/hapi.py:2422)."""
+    return list(np.asarray(LOCAL_TABLE_CACHE[TableName]["data"][ParameterName]).tolist())
+
+
+def getColumns(TableName, ParameterNames):
+    """Several columns (misc/hapi.py:2441)."""
+    return [getColumn(TableName, p) for p in ParameterNames]
+
+
+def _eval_condition(node, data, n):
+    """Row mask of a hapi condition tree: ('and'|'or', c1, c2, ...), ('not', c), ('between', x, a, b),
+    ('in', x, (v1, v2, ...)), ('==' | '!=' | '<' | '<=' | '>' | '>=', x, y); operands are column names or numbers."""
+    def operand(x):
+        if isinstance(x, str):
+            if x not in data:
+                raise Exception("select: no column %r in the table" % x)
+            return np.asarray(data[x])
+        if isinstance(x, (tuple, list)) and x and isinstance(x[0], str) and x[0].lower() in _OPS:
+            return _eval_condition(x, data, n)
+        return x
+
+    op = str(node[0]).lower()
+    if op in ("and", "&", "&&"):
+        m = np.ones(n, dtype=bool)
+        for c in node[1:]:
+            m &= _eval_condition(c, data, n)
+        return m
+    if op in ("or", "|", "||"):
+        m = np.zeros(n, dtype=bool)
+        for c in node[1:]:
+            m |= _eval_condition(c, data, n)
+        return m
+    if op in ("not", "!"):
+        return ~_eval_condition(node[1], data, n)
+    if op in ("between", "range"):
+        x = operand(node[1])
+        return (x >= operand(node[2])) & (x <= operand(node[3]))
+    if op in ("in", "subset"):
+        return np.isin(operand(node[1]), np.asarray(node[2]))
+    a, b = operand(node[1]), operand(node[2])
+    if op in ("==", "=", "eq"):
+        return np.broadcast_to(a == b, (n,)).copy()
+    if op in ("!=", "<>", "ne"):
+        return np.broadcast_to(a != b, (n,)).copy()
+    if op in ("<", "lt"):
+        return np.broadcast_to(a < b, (n,)).copy()
+    if op in ("<=", "le"):
+        return np.broadcast_to(a <= b, (n,)).copy()
+    if op in (">", "gt"):
+        return np.broadcast_to(a > b, (n,)).copy()
+    if op in (">=", "ge"):
+        return np.broadcast_to(a >= b, (n,)).copy()
+    raise NotImplementedError("select: operator %r is not supported by this minimal table layer" % (node[0],))
+
+
+_OPS = {"and", "&", "&&", "or", "|", "||", "not", "!", "between", "range", "in", "subset", "==", "=", "eq", "!=", "<>", "ne",
+        "<", "lt", "<=", "le", ">", "gt", ">=", "ge"}
+
+
+def select(TableName, DestinationTableName="__BUFFER__", ParameterNames=None, Conditions=None, Output=True, File=None):
+    """Row filter with the call shape of misc/hapi.py:2567-2600: copies the rows of `TableName` that satisfy `Conditions`
+    (a hapi condition tree of comparisons, see _eval_condition) into `DestinationTableName`; `ParameterNames` restricts
+    the columns (names only: no computed expressions); File writes the selection as a 160-character .par file when the
+    standard columns are all present. Output (printing the rows) is not reproduced."""
+    if TableName not in LOCAL_TABLE_CACHE:
+        raise Exception("%s: no such table. Check tableList() for more info." % TableName)
+    src = LOCAL_TABLE_CACHE[TableName]
+    n = int(src["header"]["number_of_rows"])
+    data = {k: np.asarray(v)[:n] for k, v in src["data"].items()}
+    mask = np.ones(n, dtype=bool) if Conditions is None else _eval_condition(Conditions, data, n)
+    cols = list(data.keys()) if not ParameterNames else list(ParameterNames)
+    out = {}
+    for c in cols:
+        if c not in data:
+            raise NotImplementedError("select: ParameterNames may only name existing columns (got %r)" % (c,))
+        out[c] = data[c][mask]
+    LOCAL_TABLE_CACHE[DestinationTableName] = {"header": {"number_of_rows": int(mask.sum()), "table_name": DestinationTableName},
+                                               "data": out}
+    if File and DestinationTableName != "__BUFFER__":
+        from . import hitran_par
+
+        if all(k in out for k, _, _ in hitran_par.FIELDS_160):
+            hitran_par.write_par(File if str(File).endswith((".par", ".data")) else str(File) + ".data", out)

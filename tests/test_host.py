@@ -286,3 +286,33 @@ def test_reference_module_surface_is_complete():
     for name in ("write_tape5", "run_LBLRTM", "read_tape12"):
         with pytest.raises(NotImplementedError):
             getattr(rt, name)()
+
+
+def test_minimal_table_layer_db_begin_and_select(tmp_path):
+    """hapi.db_begin / select / tableList as the reference's cross-section script uses them (misc/RT_gen_AbsXS_files.py:12,
+    38-44): load .par files from a folder, filter rows by a condition tree, write the selection back."""
+    from radtxfr_amd import hapi, hitran_par, synthetic
+
+    tbl = synthetic.synth_line_table(3, 500, 600.0, 1200.0)
+    hitran_par.write_par(os.path.join(tmp_path, "HITRAN2016.data"), tbl)
+    names = hapi.db_begin(str(tmp_path))
+    assert names == ["HITRAN2016"] and "HITRAN2016" in hapi.tableList()
+    n0 = hapi.LOCAL_TABLE_CACHE["HITRAN2016"]["header"]["number_of_rows"]
+    assert n0 == 500
+    cond = ("and", ("between", "nu", 700.0, 1000.0), ("==", "molec_id", 2))
+    hapi.select("HITRAN2016", Conditions=cond, DestinationTableName="CO2", File=os.path.join(tmp_path, "CO2"))
+    d = hapi.LOCAL_TABLE_CACHE["CO2"]["data"]
+    nu, mid = np.asarray(d["nu"]), np.asarray(d["molec_id"])
+    want = (np.asarray(tbl["nu"]) >= 700.0) & (np.asarray(tbl["nu"]) <= 1000.0) & (np.asarray(tbl["molec_id"]) == 2)
+    assert nu.size == int(want.sum()) > 0 and np.all(mid == 2) and nu.min() >= 700.0 and nu.max() <= 1000.0
+    back = hitran_par.read_par(os.path.join(tmp_path, "CO2.data"))
+    assert np.allclose(back["nu"], nu, atol=1e-6) and back["nu"].size == nu.size
+    hapi.select("HITRAN2016", Conditions=("or", ("<", "nu", 650.0), ("not", ("<=", "nu", 1150.0))), DestinationTableName="ends",
+                ParameterNames=["nu", "sw"])
+    e = hapi.LOCAL_TABLE_CACHE["ends"]["data"]
+    assert set(e.keys()) == {"nu", "sw"} and np.all((np.asarray(e["nu"]) < 650.0) | (np.asarray(e["nu"]) > 1150.0))
+    assert hapi.getColumn("ends", "nu") == list(np.asarray(e["nu"]).tolist())
+    hapi.dropTable("ends")
+    assert "ends" not in hapi.tableList()
+    with pytest.raises(NotImplementedError):
+        hapi.select("HITRAN2016", Conditions=("like", "nu", 1.0), DestinationTableName="x")
