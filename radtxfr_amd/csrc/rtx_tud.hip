@@ -329,9 +329,15 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
           L[q] = fmaf(t, L[q] - B, B);
         }
       } else if (__ballot(thin) == ~0ull) {
+        // 1 - 2^(OD c) as a polynomial in the stream's c with per-lane coefficients A_k = -q_k OD^k (5 multiplies per
+        // layer, shared by all streams): 5 VALU per stream instead of forming y and running em_thin (6)
+        const float o2 = od * od;
+        const float A1 = -6.9314718056e-1f * od, A2 = -2.4022650696e-1f * o2, A3 = -5.5504108665e-2f * (o2 * od);
+        const float A4 = -9.6181291076e-3f * (o2 * o2), A5 = -1.3333558146e-3f * (o2 * o2 * od);
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-          const float e = em_thin(od * cth[q]);
+          const float c = cth[q];
+          const float e = c * fmaf(c, fmaf(c, fmaf(c, fmaf(c, A5, A4), A3), A2), A1);
           L[q] = fmaf(e, B - L[q], L[q]);
         }
       } else {
