@@ -260,13 +260,15 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   {
     float S = 0.f;
     bool found = false;
-    for (int k0 = 0; k0 < nd && !found; k0 += 8) {  // 8 independent loads in flight per step, not one per layer
+    // independent loads in flight per step, not one per layer: 2 for the first step (in an absorption band the slab
+    // is usually the lowest layer or two), then 8
+    for (int k0 = 0, cnt = 2; k0 < nd && !found; k0 += cnt, cnt = 8) {
       float v[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = od_col[(size_t)(k0 + t < nd ? k0 + t : nd - 1) * a.ld];
+      for (int t = 0; t < 8; ++t) v[t] = t < cnt ? od_col[(size_t)(k0 + t < nd ? k0 + t : nd - 1) * a.ld] : 0.f;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        if (!found && k0 + t < nd) {
+        if (!found && t < cnt && k0 + t < nd) {
           S += v[t];
           if (__ballot(S * a.ang_cmin >= y_opq) == ~0ull) {
             k_start = k0 + t;
