@@ -947,3 +947,43 @@ def test_hapi_shim_option_combinations_vs_oracle(hapi):
                                                   GammaL=gl, Diluent=dil or None, IntensityThreshold=thr)
         tag = (trial, lo, step, n, Tk, p, comps, units, gl, dil, thr)
         assert np.max(want) > 0 and rel_err(xs, want) <= TOL_L, tag
+
+
+def test_drop_in_edge_cases(rt, hapi, tmp_path):
+    """Degenerate but legal calls through the drop-in API: an empty line table, one line on a 4-point grid, one layer
+    with one angle (the reference's 0/0), a sensor below the column, returnOD with save=True (ComputeTUD.npz), a grid no
+    line reaches, a 2-point grid."""
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    a = synthetic.c3_atmosphere(32)
+    args = (a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    empty = {k: np.asarray(v)[:0] for k, v in full.items()}
+    X, tau, Lu, Ld = rt.compute_TUD(1000.0, 1000.5, DVOUT=0.001, line_table=empty, **a)
+    assert X.shape == (500,) and np.all(tau == 1.0) and np.all(Lu == 0.0) and np.all(Ld == 0.0)
+    one = {k: np.asarray(v)[5000:5001] for k, v in full.items()}
+    nu0 = float(one["nu"][0])
+    X, tau, Lu, Ld = rt.compute_TUD(nu0 - 0.002, nu0 + 0.002, DVOUT=0.001, line_table=one, **a)
+    Xr, tr, ur, dr = ref.compute_TUD(one, nu0 - 0.002, nu0 + 0.002, 0.001, *args)
+    assert X.shape == (4,) and np.max(np.abs(tau - tr)) <= TOL_TAU and rel_err(Lu, ur) <= TOL_L and rel_err(Ld, dr) <= TOL_L
+    sub = synthetic.subset_table(full, 988.0, 1016.0)
+    a1 = {k: (np.asarray(v)[:1] if k != "MFs_ID" else v) for k, v in a.items()}
+    X, tau, Lu, Ld = rt.compute_TUD(1000.0, 1001.0, DVOUT=0.001, line_table=sub, N_angle=1, **a1)
+    assert np.isnan(Ld).all() and np.isfinite(tau).all() and np.isfinite(Lu).all()
+    X, tau, Lu, Ld = rt.compute_TUD(1000.0, 1001.0, DVOUT=0.001, line_table=sub, Altitudes=np.asarray([-5.0]), **a)
+    Xr, tr, ur, dr = ref.compute_TUD(sub, 1000.0, 1001.0, 0.001, *args, Altitudes=[-5.0])
+    assert np.max(np.abs(tau - tr)) <= TOL_TAU and np.max(np.abs(Lu - ur)) == 0.0 and np.array_equal(np.isnan(Ld), np.isnan(dr))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        X, od, Lu, Ld = rt.compute_TUD(1000.0, 1001.0, DVOUT=0.001, line_table=sub, returnOD=True, save=True, **a)
+    finally:
+        os.chdir(cwd)
+    Xr, odr, ur, dr = ref.compute_TUD(sub, 1000.0, 1001.0, 0.001, *args, returnOD=True)
+    assert rel_err(od, odr) <= TOL_L and rel_err(Lu, ur) <= TOL_L
+    z = np.load(os.path.join(tmp_path, "ComputeTUD.npz"))
+    assert sorted(z.files) == ["B", "Ld", "Lu", "OD", "X", "Z_s", "angles", "mu_s", "tau"] and z["OD"].shape == (X.size, 32)
+    hapi.storage2cache_from_columns("edge", sub)
+    om, xs = hapi.absorptionCoefficient_Voigt(SourceTables="edge", OmegaGrid=np.linspace(3000.0, 3001.0, 11))
+    assert xs.shape == (11,) and np.all(xs == 0.0)
+    om, xs = hapi.absorptionCoefficient_Voigt(SourceTables="edge", OmegaGrid=np.array([1000.0, 1000.5]))
+    _, xr = ref.absorptionCoefficient_Voigt(sub, OmegaGrid=np.array([1000.0, 1000.5]))
+    assert rel_err(xs, xr) <= TOL_L
