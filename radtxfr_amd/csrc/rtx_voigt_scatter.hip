@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 // Per-wave list of the lines that need point-by-point rows in this tile. The classification lanes write a 64-B
 // entry (record fields, window in u, row masks); the consumer reads it back with broadcast LDS reads, so a line
 // costs no scalar load, no scalar geometry and its constants reach the VALU as (wave-uniform) vector operands.
+#ifndef SC_ENT_CAP
 #define SC_ENT_CAP 16
+#endif
 // tile level (32 nodes over the whole tile) needs the generated tables to match the tile length
 #ifndef SC_TILE_LEVEL
 #define SC_TILE_LEVEL (RTX_SC_ROWS == 12 || RTX_SC_ROWS == 16 || RTX_SC_ROWS == 20 || RTX_SC_ROWS == 24)
