@@ -66,6 +66,9 @@ int64_t rtx_lines_count(const rtx_lines* lines);
 /* Optional speed-dependence columns SD_air / SD_self (misc/hapi.py:10884-10887), in the order of the rows given to
  * rtx_lines_create; either may be NULL (= 0). Only rtx_line_prep_profile(RTX_PROFILE_SDVOIGT) reads them. */
 int rtx_lines_set_sd(rtx_lines* lines, const double* sd_air_h, const double* sd_self_h);
+/* Optional deltap_self column: temperature dependence of the self-induced pressure shift,
+ * Shift0 += abun_self * (delta_self + deltap_self*(T - Tref)) * p (misc/hapi.py:11120-11128). NULL = 0. */
+int rtx_lines_set_deltap_self(rtx_lines* lines, const double* deltap_self_h);
 
 /* ------------------------------------------------------------------------------------------
  * Per-(line, layer) prologue, fp64. Replaces the per-line environment block of

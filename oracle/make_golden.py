@@ -103,6 +103,110 @@ def make_g11(hapi):
          SD_air=tbl["SD_air"], SD_self=tbl["SD_self"], **out)
 
 
+def make_g12(hapi):
+    """G12: the reference's own .par/.header storage layer (db_begin -> loadCache -> storage2cache ->
+    getRowObjectFromString, misc/hapi.py:1535-1672, 1718-1730, 5205-5221) on two synthetic tables whose text is
+    committed next to the fixture (tests/golden/g12_*.par|.data|.header), and its Voigt line-sum on the parsed rows.
+      g12a.par                no header (the reference writes the default 160-character one); rows with isotopologue
+                              codes '0', 'A', 'B', dropped leading zeros, blank g'/g'' fields, a short and a blank line
+      g12b.data + .header     default fields + comma-separated extras n_self, deltap_air, delta_self, deltap_self
+    """
+    import json
+    import shutil
+    import tempfile
+
+    from radtxfr_amd import hitran_par
+
+    rng = np.random.default_rng(20261012)
+    tbl = synthetic.synth_line_table(20261012, 60, 990.0, 1010.0)
+    n = tbl["nu"].size
+    tbl = dict(tbl)
+    tbl["local_iso_id"] = np.where(np.arange(n) % 11 == 5, 0, tbl["local_iso_id"])      # '0': the tenth isotopologue
+    tbl["molec_id"] = np.where(tbl["local_iso_id"] == 0, 2, tbl["molec_id"])              # (2,0) exists in ISO / TIPS
+    tbl["delta_air"] = np.where(np.arange(n) % 7 == 3, -0.0123, tbl["delta_air"])        # '-.012300'
+    tbl["gamma_air"] = np.where(np.arange(n) % 9 == 2, 0.1234, tbl["gamma_air"])         # '.1234'
+    tbl["a"] = 10.0 ** rng.uniform(-3, 2, n)
+    tbl["gp"] = rng.integers(1, 60, n).astype(float)
+    tbl["gpp"] = rng.integers(1, 60, n).astype(float)
+    tbl["global_upper_quanta"] = ["      0 1 0    "] * n
+    tbl["local_lower_quanta"] = ["  %2d  %1d  %1d     " % (k % 30, k % 5, k % 3) for k in range(n)]
+    tmp = tempfile.mkdtemp(prefix="g12_")
+    try:
+        pa = os.path.join(tmp, "g12a.par")
+        hitran_par.write_par(pa, tbl)
+        rows = open(pa).read().split("\n")[:-1]
+        assert all(len(r) == 160 for r in rows)
+        edit = list(rows)
+        edit[4] = edit[4][:2] + "A" + edit[4][3:]          # letter isotopologue code: int('A') fails -> row dropped
+        edit[9] = edit[9][:2] + "B" + edit[9][3:]
+        edit[13] = edit[13][:146] + " " * 14                # blank g' / g'': float('       ') fails -> row dropped
+        edit[21] = edit[21][:100]                           # short record
+        edit.insert(30, "")                                 # blank line
+        edit[40] = edit[40][:15] + " 1.234e-21" + edit[40][25:]   # lower-case exponent
+        text_a = "\n".join(edit) + "\n"
+        open(pa, "w").write(text_a)
+        # table b: explicit header with comma-separated extras
+        hdr = json.loads(json.dumps(hapi.HITRAN_DEFAULT_HEADER))
+        hdr["table_name"] = "g12b"
+        hdr["extra"] = ["n_self", "deltap_air", "delta_self", "deltap_self"]
+        hdr["extra_format"] = {"n_self": "%7.4f", "deltap_air": "%10.3E", "delta_self": "%9.6f", "deltap_self": "%10.3E"}
+        hdr["extra_separator"] = ","
+        ex = {"n_self": np.round(rng.uniform(0.0, 0.9, n) * (np.arange(n) % 4 != 1), 4),
+              "deltap_air": rng.uniform(-2e-5, 2e-5, n), "delta_self": np.round(rng.uniform(-0.02, 0.01, n), 6),
+              "deltap_self": rng.uniform(-5e-5, 5e-5, n)}
+        text_b = ""
+        for k, r in enumerate(rows):
+            tail = ",%7.4f,%10.3E,%9.6f,%10.3E" % (ex["n_self"][k], ex["deltap_air"][k], ex["delta_self"][k], ex["deltap_self"][k])
+            if k == 17:
+                tail = ",   oops,%10.3E,%9.6f,%10.3E" % (ex["deltap_air"][k], ex["delta_self"][k], ex["deltap_self"][k])  # -> 0.0
+            if k == 33:
+                tail = ",0.5"                                                                  # too few chunks: dropped
+            text_b += r + tail + "\n"
+        open(os.path.join(tmp, "g12b.data"), "w").write(text_b)
+        open(os.path.join(tmp, "g12b.header"), "w").write(json.dumps(hdr, indent=2))
+        quiet(hapi.db_begin, tmp)
+        out = {}
+        for name in ("g12a", "g12b"):
+            T = hapi.LOCAL_TABLE_CACHE[name]
+            out[name + "_nrows"] = T["header"]["number_of_rows"]
+            out[name + "_order"] = np.array(T["header"]["order"])
+            for col, v in T["data"].items():
+                out[name + "_" + col] = np.array(v)
+        # the reference's line-sum on what it parsed (air + self diluents: exercises n_self / deltap_* / delta_self)
+        grid = np.linspace(995.0, 1005.0, 5001)
+        for name, dil in (("g12a", {"air": 1.0}), ("g12b", {"air": 0.6, "self": 0.4})):
+            _, xs = quiet(hapi.absorptionCoefficient_Voigt, SourceTables=name, Environment={"T": 251.3, "p": 0.7},
+                          OmegaGrid=grid, HITRAN_units=True, Diluent=dil)
+            out[name + "_xs"] = xs
+        save("g12_par_tables.npz", grid_lo=995.0, grid_hi=1005.0, grid_n=5001, T=251.3, p=0.7, **out)
+        # the input text travels as data files next to the fixture
+        shutil.copy(pa, os.path.join(OUT, "g12a.par"))
+        shutil.copy(os.path.join(tmp, "g12b.data"), os.path.join(OUT, "g12b.data"))
+        shutil.copy(os.path.join(tmp, "g12b.header"), os.path.join(OUT, "g12b.header"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def make_g13(rt, hapi):
+    """G13: compute_TUD with a VECTOR theta_r (radiative_transfer.py:313, 346-365): 2 sensor altitudes x 2 slant paths
+    -> tau, L-up of shape (nX, 2, 2); 1 altitude x 3 slant paths -> (nX, 3). Thin column (as G8) so tau spans (0,1)."""
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    xlo, xhi = 1000.0, 1000.8
+    sub = synthetic.subset_table(full, xlo - 12.0, xhi + 12.0)
+    inject_table(hapi, "g13", sub)
+    rt.compute_OD = make_oracle_OD(hapi, "g13", sub)
+    a = synthetic.c3_atmosphere(32)
+    opts = dict(DVOUT=0.001, Zs=a["Zs"], Ts=a["Ts"], Ps=a["Ps"], PLs=a["PLs"], MFs_VAL=a["MFs_VAL"] * 1e-3, MFs_ID=a["MFs_ID"],
+                N_angle=30, save=False, returnOD=False)
+    th22, alt22 = np.array([0.0, 0.7]), np.array([2.0, 9.0])
+    _, tau22, Lu22, Ld22 = quiet(rt.compute_TUD, xlo, xhi, **dict(opts, theta_r=th22, Altitudes=alt22))
+    th13 = np.array([0.2, 0.5, 1.0])
+    _, tau13, Lu13, Ld13 = quiet(rt.compute_TUD, xlo, xhi, **dict(opts, theta_r=th13, Altitudes=np.asarray([500])))
+    assert tau22.shape[1:] == (2, 2) and tau13.shape[1:] == (3,)
+    save("g13_tud_slants.npz", seed=synthetic.SEED_C3, n_lines=100000, nu_lo=475.0, nu_hi=6025.0, pad=12.0, lo=xlo, hi=xhi,
+         mf_scale=1e-3, th22=th22, alt22=alt22, tau22=tau22, Lu22=Lu22, Ld22=Ld22, th13=th13, tau13=tau13, Lu13=Lu13, Ld13=Ld13)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rt, hapi, ils_gauss = load()
@@ -253,6 +357,8 @@ def main():
     make_g9(rt)
     make_g10(hapi)
     make_g11(hapi)
+    make_g12(hapi)
+    make_g13(rt, hapi)
 
 
 if __name__ == "__main__":
@@ -265,5 +371,12 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["g11"]:
         os.makedirs(OUT, exist_ok=True)
         make_g11(load()[1])
+    elif sys.argv[1:] == ["g12"]:
+        os.makedirs(OUT, exist_ok=True)
+        make_g12(load()[1])
+    elif sys.argv[1:] == ["g13"]:
+        os.makedirs(OUT, exist_ok=True)
+        r_ = load()
+        make_g13(r_[0], r_[1])
     else:
         main()

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "rtx_voigt_sum": (_i32, [_vp, _gp, _i32, _vp, _vp, _i64, _vp]),
     "rtx_sdvoigt_sum": (_i32, [_vp, _gp, _i32, _vp, _vp, _i64, _vp]),
     "rtx_lines_set_sd": (_i32, [_vp, _vp, _vp]),
+    "rtx_lines_set_deltap_self": (_i32, [_vp, _vp]),
     "rtx_voigt_tile_points": (_i32, []),
     "rtx_planck": (_i32, [_gp, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "rtx_tud": (_i32, [_vp, _i64, _gp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -111,6 +111,7 @@ struct rtx_lines {
   int n_species;
   double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
   double *sd_air, *sd_self;  // optional speed-dependence columns (rtx_lines_set_sd), NULL = 0
+  double* deltap_self;       // optional (rtx_lines_set_deltap_self), NULL = 0
   int* species;
 };
 

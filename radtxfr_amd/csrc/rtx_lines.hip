@@ -55,7 +55,7 @@ static int upload(double** dst, const double* src_h, long long n, bool zero_if_n
 extern "C" int rtx_lines_free(rtx_lines* L) {
   if (!L) return 0;
   double* p[] = {L->nu, L->sw, L->elower, L->gamma_air, L->gamma_self, L->n_air, L->n_self, L->delta_air, L->deltap_air, L->delta_self,
-                 L->sd_air, L->sd_self};
+                 L->sd_air, L->sd_self, L->deltap_self};
   for (double* q : p)
     if (q) (void)hipFree(q);
   if (L->species) (void)hipFree(L->species);
@@ -122,6 +122,15 @@ extern "C" int rtx_lines_set_sd(rtx_lines* L, const double* sd_air_h, const doub
   return 0;
 }
 
+extern "C" int rtx_lines_set_deltap_self(rtx_lines* L, const double* deltap_self_h) {
+  if (!L) RTX_FAIL("lines is NULL");
+  if (L->deltap_self) { (void)hipFree(L->deltap_self); L->deltap_self = nullptr; }
+  if (!deltap_self_h || L->n == 0) return 0;
+  RTX_HIP(hipMalloc((void**)&L->deltap_self, (size_t)L->n * sizeof(double)));
+  RTX_HIP(hipMemcpy(L->deltap_self, deltap_self_h, (size_t)L->n * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
 // ---- prep object -------------------------------------------------------------------------------------
 extern "C" int rtx_prep_free(rtx_prep* P) {
   if (!P) return 0;
@@ -179,7 +188,7 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
 
 struct PrepArgs {
   const double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
-  const double *sd_air, *sd_self;
+  const double *sd_air, *sd_self, *deltap_self;
   LineRecSD* recsd;
   const int* species;
   long long n_lines;
@@ -256,7 +265,8 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       if (a.n_self && ns == 0.0) ns = a.n_air[l];
       Gamma0 += a.dil_self * (a.gamma_self[l] * p / 1.0 * pow(tr, ns));
       const double ds = a.delta_self ? a.delta_self[l] : 0.0;
-      Shift0 += a.dil_self * ((ds + 0.0 * (T - H_TREF)) * p / 1.0);
+      const double dps = a.deltap_self ? a.deltap_self[l] : 0.0;
+      Shift0 += a.dil_self * ((ds + dps * (T - H_TREF)) * p / 1.0);
     }
     if (a.profile == RTX_PROFILE_DOPPLER) {  // no pressure broadening; Shift0 = delta_air * p (misc/hapi.py:11543), set by the host through dil_air = 1 / 0 (LineShift)
       Gamma0 = 0.0;
@@ -384,7 +394,7 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
   a.nu = L->nu; a.sw = L->sw; a.elower = L->elower; a.gamma_air = L->gamma_air; a.gamma_self = L->gamma_self;
   a.n_air = L->n_air; a.n_self = L->n_self; a.delta_air = L->delta_air; a.deltap_air = L->deltap_air;
   a.delta_self = L->delta_self; a.species = L->species;
-  a.sd_air = L->sd_air; a.sd_self = L->sd_self; a.recsd = P->recsd;
+  a.sd_air = L->sd_air; a.sd_self = L->sd_self; a.deltap_self = L->deltap_self; a.recsd = P->recsd;
   a.n_lines = L->n; a.n_layers = n_layers; a.n_species = ns;
   a.T = d; a.p = d + nT; a.qratio = d + 2 * nT; a.weight = d + 2 * nT + nQ; a.mass = d + 2 * nT + 2 * nQ;
   a.dil_air = dil_air; a.dil_self = dil_self; a.omega_wing = omega_wing; a.omega_wing_hw = omega_wing_hw;

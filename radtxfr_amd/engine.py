@@ -11,6 +11,8 @@ import torch
 
 from . import _lib, tips
 
+TUD_MAX_MU = 8  # slant paths per rtx_tud launch (include/radtxfr_hip.h)
+
 # hapi constants used for per-species / per-layer host factors (misc/hapi.py:84-92, 10163-10164)
 CBOLTS = 1.380648813e-16
 TREF = 296.0
@@ -135,6 +137,11 @@ class LineTable:
         if self.has_sd:
             sp_ = lambda k: sd[k].ctypes.data_as(C.c_void_p) if k in sd else C.c_void_p(0)
             _lib.check(lib.rtx_lines_set_sd(self._h, sp_("SD_air"), sp_("SD_self")))
+        if "deltap_self" in columns:  # misc/hapi.py:11120-11124
+            dps = np.ascontiguousarray(np.asarray(columns["deltap_self"], dtype=np.float64)[order])
+            if np.any(dps != 0.0):
+                self.cols["deltap_self"] = dps
+                _lib.check(lib.rtx_lines_set_deltap_self(self._h, dps.ctypes.data_as(C.c_void_p)))
         self._plans = {}
 
     def plan(self, n_layers, n_points):
@@ -184,14 +191,18 @@ class VoigtPlan:
             pass
 
 
-def species_factors(species, T_layers, partitionFunction=None):
-    """qratio[nS][nL] = Q(Tref)/Q(T_k) (misc/hapi.py:11069-11070) and mass[nS] (:11086)."""
+def species_factors(species, T_layers, partitionFunction=None, weight=None):
+    """qratio[nS][nL] = Q(Tref)/Q(T_k) (misc/hapi.py:11069-11070) and mass[nS] (:11086).
+    A species whose weight[s][:] is all zero is filtered out by the reference BEFORE its partition sums and mass are
+    looked up (`continue`, misc/hapi.py:11066): it keeps q = mass = 1 here, so an unselected isotopologue without TIPS
+    data, or outside the 70-3000 K range, does not raise."""
     pf = partitionFunction or tips.PYTIPS
     nS, nL = len(species), len(T_layers)
     q = np.ones((nS, nL))
     mass = np.ones(nS)
+    wz = None if weight is None else ~np.any(np.broadcast_to(np.asarray(weight, dtype=np.float64), (nS, nL)) != 0.0, axis=1)
     for s, (m, i) in enumerate(species):
-        if (m, i) == (0, 0):
+        if (m, i) == (0, 0) or (wz is not None and wz[s]):
             continue
         qref = pf(m, i, TREF)
         mass[s] = tips.molecularMass(m, i)
@@ -212,7 +223,7 @@ def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air
     p_atm = np.atleast_1d(np.asarray(p_atm, dtype=np.float64))
     nL = T.size
     if qratio is None:
-        qratio, mass = species_factors(lines.species, T, partitionFunction)
+        qratio, mass = species_factors(lines.species, T, partitionFunction, weight=weight)
     plan = lines.plan(nL, grid.n)
     T_h, T_p = _h(T)
     p_h, p_p = _h(p_atm)
@@ -268,10 +279,23 @@ def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=Fals
     T = np.atleast_1d(np.asarray(T, dtype=np.float64))
     Z = np.atleast_1d(np.asarray(Z, dtype=np.float64))
     Z_s = np.array([Altitudes], dtype=np.float64).ravel()
-    mu_s = np.array([1.0 / np.cos(theta_r)], dtype=np.float64).ravel()
+    mu_s = np.array([1.0 / np.cos(np.asarray(theta_r, dtype=np.float64))], dtype=np.float64).ravel()
     nL = T.size
     assert OD.dtype == torch.float32 and OD.is_cuda and OD.dim() == 2 and OD.shape[0] == nL and OD.shape[1] >= grid.n
     assert OD.stride(1) == 1
+    if mu_s.size > TUD_MAX_MU:
+        # more slant paths than one launch takes (radiative_transfer.py:346-356 loops over any number): blocks of
+        # TUD_MAX_MU, each a launch of its own; the downwelling (independent of mu) is simply recomputed
+        assert out is None and not per_angle, "out= / per_angle are limited to %d slant paths" % TUD_MAX_MU
+        th = np.asarray(theta_r, dtype=np.float64).ravel()
+        tau = torch.empty((Z_s.size, mu_s.size, grid.n), dtype=torch.float32, device=OD.device)
+        Lu = torch.empty_like(tau)
+        for m0 in range(0, mu_s.size, TUD_MAX_MU):
+            m1 = min(m0 + TUD_MAX_MU, mu_s.size)
+            t_c, l_c, Ld, _ = tud(OD, grid, T, Z, Altitudes=Altitudes, theta_r=th[m0:m1], N_angle=N_angle, returnOD=returnOD)
+            tau[:, m0:m1] = t_c.view(Z_s.size, m1 - m0, grid.n)
+            Lu[:, m0:m1] = l_c.view(Z_s.size, m1 - m0, grid.n)
+        return tau.view(-1, grid.n), Lu.view(-1, grid.n), Ld, (Z_s.size, mu_s.size)
     mask = np.ascontiguousarray(np.stack([(Z <= zs) for zs in Z_s]).astype(np.uint8))
     n_down = int(mask[-1].sum())  # quirk 3: nL is overwritten by the LAST altitude's count (:353, :370)
     dev = OD.device
@@ -285,14 +309,16 @@ def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=Fals
             assert t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and t.shape[0] == Z_s.size * mu_s.size
             assert t.shape[1] >= grid.n and t.stride(1) == 1 and t.stride(0) == tau.stride(0)
         assert Ld.dtype == torch.float32 and Ld.is_cuda and Ld.numel() >= grid.n and Ld.stride(0) == 1
-    Ld_ang = torch.empty((int(N_angle), grid.n), dtype=torch.float32, device=dev) if per_angle else None
+    ld_out = tau.stride(0) if tau.shape[0] > 1 else max(tau.shape[1], grid.n)
+    # rows of the per-stream output use the same leading dimension as tau / Lu (include/radtxfr_hip.h: [n_angle][ld_out])
+    Ld_ang = torch.empty((int(N_angle), ld_out), dtype=torch.float32, device=dev) if per_angle else None
     T_h, T_p = _h(T)
     mu_h, mu_p = _h(mu_s)
     _lib.check(lib.rtx_tud(_ptr(OD), OD.stride(0), grid.byref(), nL, T_p, Z_s.size, mask.ctypes.data_as(C.c_void_p),
                            mu_s.size, mu_p, n_down, int(N_angle), int(bool(returnOD)), _ptr(tau), _ptr(Lu), _ptr(Ld),
-                           _ptr(Ld_ang), tau.stride(0) if tau.shape[0] > 1 else max(tau.shape[1], grid.n), _stream_ptr()))
+                           _ptr(Ld_ang), ld_out, _stream_ptr()))
     if per_angle:
-        return tau, Lu, Ld, (Z_s.size, mu_s.size), Ld_ang
+        return tau, Lu, Ld, (Z_s.size, mu_s.size), Ld_ang[:, :grid.n]
     return tau, Lu, Ld, (Z_s.size, mu_s.size)
 
 

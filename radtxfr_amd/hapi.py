@@ -39,10 +39,36 @@ def storage2cache_from_columns(TableName, columns):
                                     "data": {k: (v.tolist() if hasattr(v, "tolist") else list(v)) for k, v in columns.items()}}
 
 
+_USED_COLS = ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air",
+              "n_self", "deltap_air", "delta_self", "deltap_self", "SD_air", "SD_self")
+_SIG_WEIGHTS = {}
+
+
+def _column_signature(v, nrow):
+    """Content fingerprint of one column (list or array): length + a dot product with fixed pseudo-random weights, so
+    that any in-place edit (a rescaled sw, a tweaked gamma_air, two rows swapped) changes it. ~30 us per 100 000-row
+    ndarray column; list columns (the reference's layout) pay the list -> array conversion."""
+    a = np.asarray(v)[:nrow]
+    if a.dtype.kind not in "fiub":
+        a = a.astype(np.float64)
+    w = _SIG_WEIGHTS.get(a.size)
+    if w is None:
+        if len(_SIG_WEIGHTS) > 16:
+            _SIG_WEIGHTS.clear()
+        w = _SIG_WEIGHTS[a.size] = np.random.default_rng(12345).uniform(0.5, 1.5, a.size)
+    return (a.size, float(np.dot(a, w)) if a.size else 0.0)
+
+
 def _device_table(names):
-    """Device LineTable for one or several cached tables (concatenated); rebuilt if the data changed."""
+    """Device LineTable for one or several cached tables (concatenated). The reference re-reads LOCAL_TABLE_CACHE on
+    every call (misc/hapi.py:11044-11125); here the device copy is reused only while a content fingerprint of EVERY
+    uploaded column is unchanged, so in-place edits of a cached table are seen (tests/test_gpu_parity.py)."""
     key = tuple(names)
-    sig = tuple((id(LOCAL_TABLE_CACHE[n]["data"].get("nu")), LOCAL_TABLE_CACHE[n]["header"]["number_of_rows"]) for n in names)
+    sig = []
+    for n in names:
+        d, nrow = LOCAL_TABLE_CACHE[n]["data"], LOCAL_TABLE_CACHE[n]["header"]["number_of_rows"]
+        sig.append((nrow,) + tuple((k, _column_signature(d[k], nrow)) for k in _USED_COLS if k in d))
+    sig = tuple(sig)
     hit = _DEVICE_TABLES.get(key)
     if hit is not None and hit[0] == sig:
         _DEVICE_TABLES[key] = _DEVICE_TABLES.pop(key)  # mark most recently used
@@ -55,8 +81,7 @@ def _device_table(names):
         keys = set(d.keys()) if keys is None else keys & set(d.keys())
         for k, v in d.items():
             cols.setdefault(k, []).append(np.asarray(v)[:nrow])
-    use = [k for k in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air",
-                       "n_self", "deltap_air", "delta_self", "SD_air", "SD_self") if k in keys]
+    use = [k for k in _USED_COLS if k in keys]
     for req in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "n_air", "delta_air"):
         if req not in use:
             raise Exception("table(s) %s lack the column %s" % (names, req))
@@ -295,123 +320,37 @@ def absorptionCoefficient_HT(Components=None, SourceTables=None, partitionFuncti
 absorptionCoefficient = absorptionCoefficient_HT  # the reference's profile selector alias, misc/hapi.py:11377
 
 
-# ---- a minimal table layer: what the reference's scripts do with hapi's database functions --------------------
-# (misc/RT_gen_AbsXS_files.py:12, 38-44: db_begin(folder); select(table, Conditions=..., DestinationTableName=..., File=...)).
-# hapi's full storage / SQL-like layer (misc/hapi.py:433-3216) is out of scope; these cover loading 160-character
-# .par / .data files from a folder and filtering rows by the comparison operators of hapi's condition trees.
+# ---- loading line files: what the reference's scripts do before the line-sum ---------------------------------------
+# (misc/RT_gen_AbsXS_files.py:12: db_begin(folder)). hapi's SQL-like layer (select / sort / group, misc/hapi.py:433-3216)
+# is out of scope; rows are filtered with NumPy on LOCAL_TABLE_CACHE[name]['data'] instead.
+VARIABLES = {"BACKEND_DATABASE_NAME": "data"}
+
+
 def db_begin(db=None):
-    """Load every `*.data` / `*.par` file of folder `db` (default 'data', as misc/hapi.py:5205-5240) into
-    LOCAL_TABLE_CACHE under the file's base name. Returns the list of table names loaded."""
-    import glob
+    """Load the tables of folder `db` (default 'data') into LOCAL_TABLE_CACHE as misc/hapi.py:5205-5221 /
+    loadCache :1718-1730 does: every `<name>.header` names a table whose rows are in `<name>.data` (else `<name>.par`);
+    a `.par` file without a header is read with the default 160-character HITRAN layout. Parsing follows the
+    reference's storage2cache row by row (radtxfr_amd/hitran_par.py). Returns the list of table names loaded."""
     import os
 
     from . import hitran_par
 
     folder = "data" if db is None else db
     os.makedirs(folder, exist_ok=True)
-    names = []
-    for path in sorted(glob.glob(os.path.join(folder, "*.data")) + glob.glob(os.path.join(folder, "*.par"))):
-        name = os.path.splitext(os.path.basename(path))[0]
-        hitran_par.storage2cache(name, path)
-        names.append(name)
     VARIABLES["BACKEND_DATABASE_NAME"] = folder
+    files = sorted(os.listdir(folder))
+    names = [f[:-len(".header")] for f in files if f.endswith(".header")]
+    names += [f[:-len(".par")] for f in files if f.endswith(".par") and f[:-len(".par")] not in names]
+    for name in names:
+        path = os.path.join(folder, name + ".data")
+        if not os.path.isfile(path):
+            path = os.path.join(folder, name + ".par")
+            if not os.path.isfile(path):
+                raise Exception('Lonely header "%s"' % path)
+        hitran_par.storage2cache(name, path)
     return names
-
-
-VARIABLES = {"BACKEND_DATABASE_NAME": "data"}
 
 
 def tableList():
     """Names of the cached tables (misc/hapi.py:5168)."""
     return list(LOCAL_TABLE_CACHE.keys())
-
-
-def dropTable(TableName):
-    """Forget a cached table (misc/hapi.py:2398)."""
-    LOCAL_TABLE_CACHE.pop(TableName, None)
-
-
-def getColumn(TableName, ParameterName):
-    """One column of a cached table as a list (misc/hapi.py:2422)."""
-    return list(np.asarray(LOCAL_TABLE_CACHE[TableName]["data"][ParameterName]).tolist())
-
-
-def getColumns(TableName, ParameterNames):
-    """Several columns (misc/hapi.py:2441)."""
-    return [getColumn(TableName, p) for p in ParameterNames]
-
-
-def _eval_condition(node, data, n):
-    """Row mask of a hapi condition tree: ('and'|'or', c1, c2, ...), ('not', c), ('between', x, a, b),
-    ('in', x, (v1, v2, ...)), ('==' | '!=' | '<' | '<=' | '>' | '>=', x, y); operands are column names or numbers."""
-    def operand(x):
-        if isinstance(x, str):
-            if x not in data:
-                raise Exception("select: no column %r in the table" % x)
-            return np.asarray(data[x])
-        if isinstance(x, (tuple, list)) and x and isinstance(x[0], str) and x[0].lower() in _OPS:
-            return _eval_condition(x, data, n)
-        return x
-
-    op = str(node[0]).lower()
-    if op in ("and", "&", "&&"):
-        m = np.ones(n, dtype=bool)
-        for c in node[1:]:
-            m &= _eval_condition(c, data, n)
-        return m
-    if op in ("or", "|", "||"):
-        m = np.zeros(n, dtype=bool)
-        for c in node[1:]:
-            m |= _eval_condition(c, data, n)
-        return m
-    if op in ("not", "!"):
-        return ~_eval_condition(node[1], data, n)
-    if op in ("between", "range"):
-        x = operand(node[1])
-        return (x >= operand(node[2])) & (x <= operand(node[3]))
-    if op in ("in", "subset"):
-        return np.isin(operand(node[1]), np.asarray(node[2]))
-    a, b = operand(node[1]), operand(node[2])
-    if op in ("==", "=", "eq"):
-        return np.broadcast_to(a == b, (n,)).copy()
-    if op in ("!=", "<>", "ne"):
-        return np.broadcast_to(a != b, (n,)).copy()
-    if op in ("<", "lt"):
-        return np.broadcast_to(a < b, (n,)).copy()
-    if op in ("<=", "le"):
-        return np.broadcast_to(a <= b, (n,)).copy()
-    if op in (">", "gt"):
-        return np.broadcast_to(a > b, (n,)).copy()
-    if op in (">=", "ge"):
-        return np.broadcast_to(a >= b, (n,)).copy()
-    raise NotImplementedError("select: operator %r is not supported by this minimal table layer" % (node[0],))
-
-
-_OPS = {"and", "&", "&&", "or", "|", "||", "not", "!", "between", "range", "in", "subset", "==", "=", "eq", "!=", "<>", "ne",
-        "<", "lt", "<=", "le", ">", "gt", ">=", "ge"}
-
-
-def select(TableName, DestinationTableName="__BUFFER__", ParameterNames=None, Conditions=None, Output=True, File=None):
-    """Row filter with the call shape of misc/hapi.py:2567-2600: copies the rows of `TableName` that satisfy `Conditions`
-    (a hapi condition tree of comparisons, see _eval_condition) into `DestinationTableName`; `ParameterNames` restricts
-    the columns (names only: no computed expressions); File writes the selection as a 160-character .par file when the
-    standard columns are all present. Output (printing the rows) is not reproduced."""
-    if TableName not in LOCAL_TABLE_CACHE:
-        raise Exception("%s: no such table. Check tableList() for more info." % TableName)
-    src = LOCAL_TABLE_CACHE[TableName]
-    n = int(src["header"]["number_of_rows"])
-    data = {k: np.asarray(v)[:n] for k, v in src["data"].items()}
-    mask = np.ones(n, dtype=bool) if Conditions is None else _eval_condition(Conditions, data, n)
-    cols = list(data.keys()) if not ParameterNames else list(ParameterNames)
-    out = {}
-    for c in cols:
-        if c not in data:
-            raise NotImplementedError("select: ParameterNames may only name existing columns (got %r)" % (c,))
-        out[c] = data[c][mask]
-    LOCAL_TABLE_CACHE[DestinationTableName] = {"header": {"number_of_rows": int(mask.sum()), "table_name": DestinationTableName},
-                                               "data": out}
-    if File and DestinationTableName != "__BUFFER__":
-        from . import hitran_par
-
-        if all(k in out for k, _, _ in hitran_par.FIELDS_160):
-            hitran_par.write_par(File if str(File).endswith((".par", ".data")) else str(File) + ".data", out)

@@ -195,13 +195,11 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     f = lambda x: np.array([x]).ravel()
     Z_s = f(o["Altitudes"])
     mu_s = f(1.0 / np.cos(o["theta_r"]))
-    if mu_s.size != 1:
-        raise NotImplementedError("theta_r must be a scalar (one slant path per call)")
     X_ = make_spectral_axis(Xmin, Xmax, o["DVOUT"])
     grid = engine.Grid(Xmin, Xmax, X_.size)
     tbl = _resolve_table(o.get("line_table"))
     OD = engine.optical_depths(tbl, grid, T, P, PL, MF, ID)  # [nL][nX] float32 on the device
-    res = engine.tud(OD, grid, T, Z, Altitudes=Z_s, theta_r=float(np.asarray(o["theta_r"]).ravel()[0]), N_angle=nA,
+    res = engine.tud(OD, grid, T, Z, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64), N_angle=nA,
                      returnOD=bool(o["returnOD"]), per_angle=bool(o["save"]))
     tau, Lu, Ld, (nZ, nMu) = res[:4]
     tau_ = tau.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1)

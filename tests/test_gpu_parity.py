@@ -987,3 +987,76 @@ def test_drop_in_edge_cases(rt, hapi, tmp_path):
     om, xs = hapi.absorptionCoefficient_Voigt(SourceTables="edge", OmegaGrid=np.array([1000.0, 1000.5]))
     _, xr = ref.absorptionCoefficient_Voigt(sub, OmegaGrid=np.array([1000.0, 1000.5]))
     assert rel_err(xs, xr) <= TOL_L
+
+
+# ----------------------------------------------------------------------- round 2: .par reader -> device, slant vectors
+def test_g12_par_files_to_device_line_sum(hapi, golden):
+    """SURVEY 8f row 3 end to end: .par / .data + .header files -> hapi.db_begin (the reference's storage2cache rules,
+    radtxfr_amd/hitran_par.py) -> device line table -> absorptionCoefficient_Voigt, against what the REFERENCE computed
+    from its own parse of the same files (golden G12): air broadening on the header-less .par (isotopologue code '0'
+    -> (2, 0)), air + self with the n_self / deltap_air / delta_self / deltap_self extras on the .data table."""
+    from conftest import GOLDEN
+    g = golden("g12_par_tables.npz")
+    names = hapi.db_begin(GOLDEN)
+    assert set(names) == {"g12a", "g12b"}
+    grid = np.linspace(float(g["grid_lo"]), float(g["grid_hi"]), int(g["grid_n"]))
+    env = {"T": float(g["T"]), "p": float(g["p"])}
+    _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="g12a", Environment=env, OmegaGrid=grid, HITRAN_units=True)
+    assert rel_err(xs, g["g12a_xs"]) <= TOL_L
+    _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="g12b", Environment=env, OmegaGrid=grid, HITRAN_units=True,
+                                             Diluent={"air": 0.6, "self": 0.4})
+    assert rel_err(xs, g["g12b_xs"]) <= TOL_L
+    # without the optional columns the answer differs visibly: they are really used
+    d = hapi.LOCAL_TABLE_CACHE["g12b"]["data"]
+    hapi.LOCAL_TABLE_CACHE["g12b_plain"] = {"header": {"number_of_rows": len(d["nu"])},
+                                            "data": {k: v for k, v in d.items() if k not in ("n_self", "deltap_air", "delta_self", "deltap_self")}}
+    _, xs_plain = hapi.absorptionCoefficient_Voigt(SourceTables="g12b_plain", Environment=env, OmegaGrid=grid,
+                                                   Diluent={"air": 0.6, "self": 0.4})
+    assert rel_err(xs_plain, g["g12b_xs"]) > 1e-3
+    for n in ("g12a", "g12b", "g12b_plain"):
+        hapi.LOCAL_TABLE_CACHE.pop(n)
+
+
+def test_cached_device_table_sees_in_place_edits(hapi):
+    """the reference re-reads LOCAL_TABLE_CACHE on every call (misc/hapi.py:11044-11125); the device copy
+    here must not survive an in-place edit of ANY column."""
+    tbl = synthetic.synth_line_table(11, 300, 995.0, 1005.0)
+    hapi.LOCAL_TABLE_CACHE["edit"] = {"header": {"number_of_rows": 300}, "data": {k: np.array(v) for k, v in tbl.items()}}
+    grid = np.linspace(998.0, 1002.0, 4001)
+    kw = dict(SourceTables="edit", Environment={"T": 280.0, "p": 0.8}, OmegaGrid=grid)
+    _, x0 = hapi.absorptionCoefficient_Voigt(**kw)
+    hapi.LOCAL_TABLE_CACHE["edit"]["data"]["sw"] *= 2.0                      # same array object, same row count
+    _, x1 = hapi.absorptionCoefficient_Voigt(**kw)
+    assert rel_err(x1, 2.0 * x0) <= 1e-6
+    hapi.LOCAL_TABLE_CACHE["edit"]["data"]["gamma_air"][:] = 0.5 * hapi.LOCAL_TABLE_CACHE["edit"]["data"]["gamma_air"]
+    _, x2 = hapi.absorptionCoefficient_Voigt(**kw)
+    t2 = dict(tbl, sw=tbl["sw"] * 2.0, gamma_air=tbl["gamma_air"] * 0.5)
+    _, x2r = ref.absorptionCoefficient_Voigt(t2, T=280.0, p=0.8, OmegaGrid=grid)
+    assert rel_err(x2, x2r) <= TOL_L and rel_err(x2, x1) > 1e-2
+    hapi.LOCAL_TABLE_CACHE.pop("edit")
+
+
+def test_g13_compute_tud_vector_theta_golden(rt, golden):
+    """Vector theta_r through the drop-in (radiative_transfer.py:313, 346-365): (nX, nZ, nMu) for 2 altitudes x 2
+    slants, (nX, nMu) for one altitude x 3 slants -- the reference's squeeze rules -- against golden G13; and more
+    slant paths than one rtx_tud launch takes (9 > 8) against the oracle."""
+    g = golden("g13_tud_slants.npz")
+    full = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    lo, hi = float(g["lo"]), float(g["hi"])
+    sub = synthetic.subset_table(full, lo - float(g["pad"]), hi + float(g["pad"]))
+    a = synthetic.c3_atmosphere(32)
+    a["MFs_VAL"] = a["MFs_VAL"] * float(g["mf_scale"])
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, theta_r=g["th22"], Altitudes=g["alt22"], **a)
+    assert tau.shape == Lu.shape == (X.size, 2, 2) and Ld.shape == (X.size,)
+    assert np.max(np.abs(tau - g["tau22"])) <= TOL_TAU
+    assert rel_err(Lu, g["Lu22"]) <= TOL_L and rel_err(Ld, g["Ld22"]) <= TOL_L
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, theta_r=g["th13"], Altitudes=np.asarray([500]), **a)
+    assert tau.shape == Lu.shape == (X.size, 3)
+    assert np.max(np.abs(tau - g["tau13"])) <= TOL_TAU
+    assert rel_err(Lu, g["Lu13"]) <= TOL_L and rel_err(Ld, g["Ld13"]) <= TOL_L
+    th9 = np.linspace(0.0, 1.2, 9)
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, theta_r=th9, Altitudes=np.asarray([3.0, 9.0]), **a)
+    Xr, tau_r, Lu_r, Ld_r = ref.compute_TUD(sub, lo, hi, 0.001, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"],
+                                            Altitudes=[3.0, 9.0], theta_r=th9)
+    assert tau.shape == tau_r.shape == (X.size, 2, 9)
+    assert np.max(np.abs(tau - tau_r)) <= TOL_TAU and rel_err(Lu, Lu_r) <= TOL_L and rel_err(Ld, Ld_r) <= TOL_L

@@ -144,12 +144,50 @@ def test_layer_weights_follow_the_od_contract():
     assert np.all(w[3] == 0) and np.allclose(p_atm, [1.0, 50000.0 / 101325.0])
 
 
-def test_hitran_par_roundtrip(tmp_path):
-    """the 160-column .par layout (misc/hapi.py:468-559) written and parsed back; synthetic tables
-    are already rounded to .par precision, so the round trip is exact."""
+def _check_table_against_golden(cols, header, g, name):
+    order = [str(x) for x in g[name + "_order"]]
+    assert header["order"] == order and header["number_of_rows"] == int(g[name + "_nrows"])
+    for k in order:
+        want = g[name + "_" + k]
+        if want.dtype.kind in "US":
+            assert list(cols[k]) == [str(x) for x in want], k
+        else:
+            got = np.asarray(cols[k])
+            assert got.dtype.kind == want.dtype.kind and np.array_equal(got, want), k  # bit-exact: same int()/float()
+
+
+def test_par_reader_equals_reference_storage2cache(golden):
+    """SURVEY 8f row 3. tests/golden/g12a.par and g12b.data/.header are synthetic line files; g12_par_tables.npz holds
+    what the REFERENCE's db_begin -> storage2cache -> getRowObjectFromString (misc/hapi.py:1535-1672) made of them
+    (oracle/make_golden.py:make_g12). Every column must agree exactly, including the rows the reference drops:
+    isotopologue codes 'A'/'B' (int() fails), blank g'/g'' fields, a truncated record, a blank line, a row with too
+    few comma-separated extras -- and what it keeps: code '0' -> local_iso_id 0, '-.012300', '.1234', ' 1.234e-21',
+    an unparsable extra -> 0.0."""
+    from radtxfr_amd import hapi, hitran_par
+    from conftest import GOLDEN
+    g = golden("g12_par_tables.npz")
+    ha, ca = hitran_par.read_table(os.path.join(GOLDEN, "g12a.par"))
+    _check_table_against_golden(ca, ha, g, "g12a")
+    assert 0 in ca["local_iso_id"] and ca["delta_air"].min() == -0.0123 and 0.1234 in ca["gamma_air"] and 1.234e-21 in ca["sw"]
+    hb, cb = hitran_par.read_table(os.path.join(GOLDEN, "g12b.data"))
+    _check_table_against_golden(cb, hb, g, "g12b")
+    assert "extra" not in hb and hb["format"]["deltap_self"] == "%10.3E"
+    # db_begin: the folder scan of loadCache (misc/hapi.py:1718-1730) -- headers first, then header-less .par files
+    names = hapi.db_begin(GOLDEN)
+    assert names == ["g12b", "g12a"] and set(names) <= set(hapi.tableList())
+    assert hapi.LOCAL_TABLE_CACHE["g12a"]["header"]["number_of_rows"] == int(g["g12a_nrows"])
+    assert np.array_equal(hapi.LOCAL_TABLE_CACHE["g12b"]["data"]["n_self"], g["g12b_n_self"])
+    for n in names:
+        hapi.LOCAL_TABLE_CACHE.pop(n)
+
+
+def test_par_writer_records_parse_back(tmp_path):
+    """write_par emits full 160-character records (g'/g'' as %7.1f: left blank, the reference's parser drops the row);
+    synthetic tables are already rounded to .par precision, so the round trip through the vectorised reader is exact.
+    A HITRAN-style record typed by hand parses field by field (columns per HITRAN_FORMAT_160, misc/hapi.py:468-489)."""
     from radtxfr_amd import hapi, hitran_par, synthetic
     tbl = synthetic.synth_line_table(7, 500, 600.0, 1400.0)
-    tbl["local_iso_id"][:3] = [10, 11, 12]  # '0', 'A', 'B' codes
+    tbl["local_iso_id"][:2] = [0, 9]
     p = tmp_path / "t.par"
     hitran_par.write_par(str(p), tbl)
     lines = open(p).read().splitlines()
@@ -157,19 +195,46 @@ def test_hitran_par_roundtrip(tmp_path):
     got = hitran_par.storage2cache("t", str(p))
     for k in ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air"):
         assert np.array_equal(got[k], tbl[k]), k
-    assert hapi.LOCAL_TABLE_CACHE["t"]["header"]["number_of_rows"] == 500
-    # a HITRAN-style record typed by hand (columns per HITRAN_FORMAT_160)
-    rec = " 2" + "1" + "  667.661431" + " 1.152E-19" + " 1.518E+00" + ".0720" + "0.094" + "    3.9032" + "0.75" + "-.000870"
-    assert len(rec) == 67
+    assert hapi.LOCAL_TABLE_CACHE.pop("t")["header"]["number_of_rows"] == 500
+    with pytest.raises(ValueError):
+        hitran_par.write_par(str(p), dict(tbl, local_iso_id=np.full(500, 11)))
+    rec = (" 2" + "1" + "  667.661431" + " 1.152E-19" + " 1.518E+00" + ".0720" + "0.094" + "    3.9032" + "0.75" + "-.000870"
+           + " " * 79 + "    3.0" + "    5.0")
+    assert len(rec) == 160
     q = tmp_path / "one.par"
-    q.write_text(rec.ljust(160) + "\n")
+    q.write_text(rec + "\n" + rec[:146] + "\n")  # second record without g'/g'': dropped
     one = hitran_par.read_par(str(q))
-    assert (one["molec_id"][0], one["local_iso_id"][0]) == (2, 1)
+    assert one["nu"].size == 1 and (one["molec_id"][0], one["local_iso_id"][0]) == (2, 1)
     assert one["nu"][0] == 667.661431 and one["sw"][0] == 1.152e-19 and one["gamma_air"][0] == 0.072
     assert one["gamma_self"][0] == 0.094 and one["elower"][0] == 3.9032 and one["n_air"][0] == 0.75 and one["delta_air"][0] == -0.00087
-    with pytest.raises(ValueError):
-        q.write_text("too short\n")
-        hitran_par.read_par(str(q))
+    assert one["gp"][0] == 3.0 and one["gpp"][0] == 5.0
+
+
+def test_species_factors_skip_unselected_species():
+    """misc/hapi.py:11066: a line whose (M, I) is not among the Components is skipped before PYTIPS / molecularMass are
+    called, so an isotopologue without TIPS data only raises when it is actually selected."""
+    from radtxfr_amd import engine
+    species = [(1, 1), (2, 1), (99, 1)]
+    T = np.array([250.0, 296.0])
+    w = np.array([[1.0, 1.0], [0.5, 0.0], [0.0, 0.0]])
+    q, mass = engine.species_factors(species, T, weight=w)
+    assert q[2].tolist() == [1.0, 1.0] and mass[2] == 1.0 and q[0, 1] == 1.0 and q[0, 0] > 1.0
+    with pytest.raises(Exception):
+        engine.species_factors(species, T)
+    with pytest.raises(Exception):
+        engine.species_factors(species, np.array([60.0]), weight=np.ones((3, 1)))
+
+
+def test_device_table_signature_covers_every_column():
+    """hapi._device_table's cache key is a content fingerprint of all uploaded columns: editing sw (or any other
+    column) in place, or swapping two rows, changes it (id(nu) + row count alone went stale)."""
+    from radtxfr_amd import hapi
+    a = np.linspace(1.0, 2.0, 1000)
+    s0 = hapi._column_signature(a, 1000)
+    b = a.copy()
+    b[[3, 700]] = b[[700, 3]]
+    assert hapi._column_signature(b, 1000) != s0 and hapi._column_signature(a * 1.0000001, 1000) != s0
+    assert hapi._column_signature(a.tolist(), 1000) == s0 and hapi._column_signature(a, 999) != s0
 
 
 def test_chebyshev_tables_match_generator_and_error_bounds():
@@ -286,33 +351,3 @@ def test_reference_module_surface_is_complete():
     for name in ("write_tape5", "run_LBLRTM", "read_tape12"):
         with pytest.raises(NotImplementedError):
             getattr(rt, name)()
-
-
-def test_minimal_table_layer_db_begin_and_select(tmp_path):
-    """hapi.db_begin / select / tableList as the reference's cross-section script uses them (misc/RT_gen_AbsXS_files.py:12,
-    38-44): load .par files from a folder, filter rows by a condition tree, write the selection back."""
-    from radtxfr_amd import hapi, hitran_par, synthetic
-
-    tbl = synthetic.synth_line_table(3, 500, 600.0, 1200.0)
-    hitran_par.write_par(os.path.join(tmp_path, "HITRAN2016.data"), tbl)
-    names = hapi.db_begin(str(tmp_path))
-    assert names == ["HITRAN2016"] and "HITRAN2016" in hapi.tableList()
-    n0 = hapi.LOCAL_TABLE_CACHE["HITRAN2016"]["header"]["number_of_rows"]
-    assert n0 == 500
-    cond = ("and", ("between", "nu", 700.0, 1000.0), ("==", "molec_id", 2))
-    hapi.select("HITRAN2016", Conditions=cond, DestinationTableName="CO2", File=os.path.join(tmp_path, "CO2"))
-    d = hapi.LOCAL_TABLE_CACHE["CO2"]["data"]
-    nu, mid = np.asarray(d["nu"]), np.asarray(d["molec_id"])
-    want = (np.asarray(tbl["nu"]) >= 700.0) & (np.asarray(tbl["nu"]) <= 1000.0) & (np.asarray(tbl["molec_id"]) == 2)
-    assert nu.size == int(want.sum()) > 0 and np.all(mid == 2) and nu.min() >= 700.0 and nu.max() <= 1000.0
-    back = hitran_par.read_par(os.path.join(tmp_path, "CO2.data"))
-    assert np.allclose(back["nu"], nu, atol=1e-6) and back["nu"].size == nu.size
-    hapi.select("HITRAN2016", Conditions=("or", ("<", "nu", 650.0), ("not", ("<=", "nu", 1150.0))), DestinationTableName="ends",
-                ParameterNames=["nu", "sw"])
-    e = hapi.LOCAL_TABLE_CACHE["ends"]["data"]
-    assert set(e.keys()) == {"nu", "sw"} and np.all((np.asarray(e["nu"]) < 650.0) | (np.asarray(e["nu"]) > 1150.0))
-    assert hapi.getColumn("ends", "nu") == list(np.asarray(e["nu"]).tolist())
-    hapi.dropTable("ends")
-    assert "ends" not in hapi.tableList()
-    with pytest.raises(NotImplementedError):
-        hapi.select("HITRAN2016", Conditions=("like", "nu", 1.0), DestinationTableName="x")

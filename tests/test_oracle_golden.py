@@ -206,3 +206,45 @@ def test_g11_sdvoigt(golden):
     close(xs, g["xs_d"], rtol=1e-11, atol=1e-30)
     _, xv = ref.absorptionCoefficient_Voigt(tbl, T=250.0, p=0.3, OmegaGrid=grid)
     assert np.max(np.abs(xv - g["xs_a"])) / np.max(xv) > 5e-3  # the speed dependence is not a rounding-level effect here
+
+
+def _g12_tables(g):
+    """Numeric line-table columns exactly as the reference parsed them (tests/golden/g12_par_tables.npz)."""
+    cols = ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air")
+    a = {k: g["g12a_" + k] for k in cols}
+    b = {k: g["g12b_" + k] for k in cols + ("n_self", "deltap_air", "delta_self", "deltap_self")}
+    return a, b
+
+
+def test_g12_voigt_on_parsed_par_tables(golden):
+    """The reference's Voigt line-sum on the rows ITS parser kept (air only; air + self with n_self, deltap_air,
+    delta_self, deltap_self): pins the oracle's optional-column handling (misc/hapi.py:11090-11128)."""
+    g = golden("g12_par_tables.npz")
+    a, b = _g12_tables(g)
+    grid = np.linspace(float(g["grid_lo"]), float(g["grid_hi"]), int(g["grid_n"]))
+    _, xs = ref.absorptionCoefficient_Voigt(a, T=float(g["T"]), p=float(g["p"]), OmegaGrid=grid)
+    close(xs, g["g12a_xs"], rtol=1e-11, atol=1e-40)
+    _, xs = ref.absorptionCoefficient_Voigt(b, T=float(g["T"]), p=float(g["p"]), OmegaGrid=grid, Diluent={"air": 0.6, "self": 0.4})
+    close(xs, g["g12b_xs"], rtol=1e-11, atol=1e-40)
+    assert np.any(b["n_self"] == 0.0) and np.any(b["deltap_self"] != 0.0)
+
+
+def test_g13_tud_vector_theta(golden):
+    """Vector theta_r (radiative_transfer.py:313, 346-365): (nX, nZ, nMu) and the (nX, nMu) squeeze."""
+    g = golden("g13_tud_slants.npz")
+    full = synthetic.synth_line_table(int(g["seed"]), int(g["n_lines"]), float(g["nu_lo"]), float(g["nu_hi"]))
+    lo, hi = float(g["lo"]), float(g["hi"])
+    sub = synthetic.subset_table(full, lo - float(g["pad"]), hi + float(g["pad"]))
+    a = synthetic.c3_atmosphere(32)
+    mf = a["MFs_VAL"] * float(g["mf_scale"])
+    X, tau, Lu, Ld = ref.compute_TUD(sub, lo, hi, 0.001, a["Zs"], a["Ts"], a["Ps"], a["PLs"], mf, a["MFs_ID"],
+                                     Altitudes=g["alt22"], theta_r=g["th22"])
+    assert tau.shape == (X.size, 2, 2)
+    close(tau, g["tau22"], rtol=1e-11)
+    close(Lu, g["Lu22"], rtol=1e-11)
+    close(Ld, g["Ld22"], rtol=1e-11)
+    X, tau, Lu, Ld = ref.compute_TUD(sub, lo, hi, 0.001, a["Zs"], a["Ts"], a["Ps"], a["PLs"], mf, a["MFs_ID"], theta_r=g["th13"])
+    assert tau.shape == (X.size, 3)
+    close(tau, g["tau13"], rtol=1e-11)
+    close(Lu, g["Lu13"], rtol=1e-11)
+    close(Ld, g["Ld13"], rtol=1e-11)
