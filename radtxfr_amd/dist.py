@@ -29,6 +29,19 @@ def subset_lines(columns, x_lo, x_hi, reach):
     return {k: np.asarray(v)[m] for k, v in columns.items()}
 
 
+def _all_gather_flat(send, world, group=None):
+    """ONE all_gather_into_tensor of equal flat blocks. RCCL ("nccl") gathers device buffers in place over xGMI; the
+    gloo backend (CPU tests, and rehearsals of the N > 1 path with several ranks sharing one GPU) has no device
+    all-gather, so device blocks are staged through the host there."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        recv = torch.empty((world * send.numel(),), dtype=send.dtype)
+        dist.all_gather_into_tensor(recv, send.cpu(), group=group)
+        return recv.to(send.device)
+    recv = torch.empty((world * send.numel(),), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv
+
+
 def all_gather_spectra(local, n_total, group=None):
     """local: [C][n_loc] tensor (C stacked spectra of this rank's chunk, any device the backend supports).
     Returns [C][n_total] on every rank. One all_gather_into_tensor of a padded [C][per] block."""
@@ -41,8 +54,7 @@ def all_gather_spectra(local, n_total, group=None):
     C = local.shape[0]
     send = local if n_loc == per else torch.nn.functional.pad(local, (0, per - n_loc))
     send = send.contiguous().view(-1)  # flat buffers: accepted by both the RCCL and the gloo backends
-    recv = torch.empty((world * C * per,), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = _all_gather_flat(send, world, group)
     return recv.view(world, C, per).permute(1, 0, 2).reshape(C, world * per)[:, :n_total]
 
 
@@ -98,8 +110,7 @@ def all_gather_rows(local, n_rows_total, group=None):
     assert local.shape[0] == n_loc, (local.shape, n_loc)
     M = local.shape[1]
     send = local if n_loc == per else torch.cat([local, local.new_zeros((per - n_loc, M))])
-    recv = torch.empty((world * per * M,), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send.contiguous().view(-1), group=group)
+    recv = _all_gather_flat(send.contiguous().view(-1), world, group)
     return recv.view(world * per, M)[:n_rows_total]
 
 
@@ -113,3 +124,51 @@ def hsi_cube_sharded(compute_bands, n_bands_total, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     b0, nb, _ = shard_bounds(n_bands_total, world, rank)
     return all_gather_rows(compute_bands(b0, b0 + nb), n_bands_total, group)
+
+
+def hsi_cube_from_atmosphere(Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, PLs, MFs_VAL, MFs_ID, Xk, endmembers, kidx, frac, Tpix,
+                             resFactor=2, Altitudes=(500,), theta_r=0.0, N_angle=30, group=None):
+    """Config C5 end to end across the ranks of `group` (the reference's single-process model is
+    LWIR_HSI_Generator.py:109-179 on a stored TUD): line table + atmosphere -> monochromatic tau, L-up, L-down on the
+    MAKO span -> per-pixel at-sensor radiance -> triangle ILS -> cube [n_bands][n_pixels].
+
+    The cube is cut along the BAND axis. Rank r owns bands [b0, b1) and computes the whole path -- prologue, line-sum,
+    TUD, band moments, pixel cube -- ONLY on the wavenumbers under those bands' triangles (centre +- sigma); neighbouring
+    ranks recompute the ~3 % of points their edge triangles share instead of exchanging them. ONE all-gather assembles
+    the cube on every rank. Shards start on a line-sum tile boundary of the full axis and every rank keeps the whole
+    line table of the span, so each rank's numbers are bit-identical to the single-rank run (same tiles, same
+    candidate lines, same summation order).
+
+    Xk [nk] knot axis, endmembers [nk][nEnd] float32, kidx [nPix][nMix] int32, frac [nPix][nMix] float32, Tpix [nPix]
+    float64: device tensors (sensor.hsi_cube). Returns (X_out [nB] NumPy, cube [nB][nPix] float32 device)."""
+    from . import _lib, engine, sensor
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_total = int(np.ceil((Xmax - Xmin) / DVOUT))
+    grid_full = engine.Grid(Xmin, Xmax, n_total)
+    X_out, centre, sigma = sensor.mako_bands(grid_full.x_at(0), grid_full.x_at(n_total - 1), resFactor)
+    nB = X_out.size
+    b0, nb, _ = shard_bounds(nB, world, rank)
+    dev = endmembers.device
+    if nb == 0:
+        local = torch.empty((0, kidx.shape[0]), dtype=torch.float32, device=dev)
+    else:
+        tile = int(_lib.load().rtx_voigt_tile_points())
+        x_lo = float(np.min(centre[b0:b0 + nb] - sigma[b0:b0 + nb]))
+        x_hi = float(np.max(centre[b0:b0 + nb] + sigma[b0:b0 + nb]))
+        i_lo = max(0, int(np.floor((x_lo - Xmin) / grid_full.step)) - 1)
+        i_lo -= i_lo % tile  # start on a tile boundary of the full axis ...
+        i_hi = int(np.ceil((x_hi - Xmin) / grid_full.step)) + 2
+        i_hi = min(n_total, i_hi + (-i_hi) % tile)  # ... and end on one (or at the end of the axis)
+        grid = grid_full.shard(i_lo, i_hi - i_lo)
+        lines = line_table if isinstance(line_table, engine.LineTable) else engine.LineTable(line_table)
+        try:
+            OD = engine.optical_depths(lines, grid, Ts, Ps, PLs, MFs_VAL, MFs_ID)
+            tau, Lu, Ld, _ = engine.tud(OD, grid, Ts, Zs, Altitudes=Altitudes, theta_r=theta_r, N_angle=N_angle)
+            local = sensor.hsi_cube(grid, tau[0], Lu[0], Ld, Xk, endmembers, kidx, frac, Tpix, resFactor=resFactor,
+                                    bands=(X_out[b0:b0 + nb], centre[b0:b0 + nb], sigma[b0:b0 + nb]))[1]
+        finally:
+            if lines is not line_table:
+                torch.cuda.synchronize()
+                lines.close()
+    return X_out, all_gather_rows(local, nB, group)

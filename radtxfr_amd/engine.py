@@ -196,18 +196,25 @@ def species_factors(species, T_layers, partitionFunction=None, weight=None):
     A species whose weight[s][:] is all zero is filtered out by the reference BEFORE its partition sums and mass are
     looked up (`continue`, misc/hapi.py:11066): it keeps q = mass = 1 here, so an unselected isotopologue without TIPS
     data, or outside the 70-3000 K range, does not raise."""
-    pf = partitionFunction or tips.PYTIPS
     nS, nL = len(species), len(T_layers)
     q = np.ones((nS, nL))
     mass = np.ones(nS)
     wz = None if weight is None else ~np.any(np.broadcast_to(np.asarray(weight, dtype=np.float64), (nS, nL)) != 0.0, axis=1)
-    for s, (m, i) in enumerate(species):
-        if (m, i) == (0, 0) or (wz is not None and wz[s]):
-            continue
-        qref = pf(m, i, TREF)
-        mass[s] = tips.molecularMass(m, i)
-        for k, T in enumerate(T_layers):
-            q[s, k] = qref / pf(m, i, float(T))
+    use = [s for s, mi in enumerate(species) if mi != (0, 0) and not (wz is not None and wz[s])]
+    if not use:
+        return q, mass
+    for s in use:
+        mass[s] = tips.molecularMass(*species[s])
+    if partitionFunction is None or partitionFunction is tips.PYTIPS:
+        # default TIPS-2011: all (species, layer) pairs in one vectorised pass, plus Q(Tref) as an extra column
+        Q = tips.partition_sums([species[s] for s in use], np.concatenate([np.asarray(T_layers, dtype=np.float64), [TREF]]))
+        q[use] = Q[:, -1:] / Q[:, :-1]
+    else:
+        for s in use:
+            m, i = species[s]
+            qref = partitionFunction(m, i, TREF)
+            for k, T in enumerate(T_layers):
+                q[s, k] = qref / partitionFunction(m, i, float(T))
     return q, mass
 
 

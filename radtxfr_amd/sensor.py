@@ -78,17 +78,19 @@ def chebyshev_lagrange(Q):
     return s, coef
 
 
-def hsi_cube(grid, tau, La, Ld, Xk, endmembers, kidx, frac, Tpix, resFactor=2, band_slice=None, Q=5):
+def hsi_cube(grid, tau, La, Ld, Xk, endmembers, kidx, frac, Tpix, resFactor=2, band_slice=None, Q=5, bands=None):
     """Config C5: band radiances of an HSI cube whose pixels each have an emissivity mixture and a surface
     temperature of their own (LWIR_HSI_Generator.py:151-167), from monochromatic tau/La/Ld through the
     triangle ILS (rt.ILS_MAKO with resFactor).
 
     endmembers [nk][nEnd] float32 device (knot spectra), kidx [nPix][nMix] int32, frac [nPix][nMix] float32,
     Tpix [nPix] float64 -- device tensors. band_slice: (b0, b1) to compute only a band-aligned shard.
+    bands = (X_out, centre, sigma): explicit band list (mako_bands() of the FULL spectral axis) when `grid` is only the
+    wavenumber shard under those bands (dist.hsi_cube_from_atmosphere); default: the bands inside `grid`.
     Returns (X_out [nB] NumPy, cube [nB][nPix] float32 device)."""
     lib = _lib.load()
     dev = tau.device
-    X_out, centre, sigma = mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
+    X_out, centre, sigma = bands if bands is not None else mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
     if band_slice is not None:
         X_out, centre, sigma = X_out[band_slice[0]:band_slice[1]], centre[band_slice[0]:band_slice[1]], sigma[band_slice[0]:band_slice[1]]
     nB, nk, nEnd = X_out.size, len(Xk), endmembers.shape[1]

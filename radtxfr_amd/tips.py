@@ -69,6 +69,58 @@ def partition_sum(M, I, T):
 PYTIPS = partition_sum
 
 
+def partition_sums(species, T):
+    """Q[s][k] = partition_sum(*species[s], T[k]) for all species and temperatures at once: the same 3-/4-point
+    Lagrange arithmetic in the same order (bit-identical to the scalar routine, tests/test_host.py), as a few dozen
+    NumPy operations on [nS][nT] arrays instead of nS*nT Python calls -- this runs once per atmosphere on the host
+    inside the timed step of bench.py."""
+    T = np.atleast_1d(np.asarray(T, dtype=np.float64))
+    if T.size and (T.min() < 70.0 or T.max() > 3000.0):
+        raise Exception("TIPS: T must be between 70K and 3000K.")
+    t = _tab()
+    A = t["tdat"]
+    npt = A.size
+    rows = []
+    for (M, I) in species:
+        key = (int(M), int(I))
+        if key not in t["q"] or not np.isfinite(t["q"][key][0]):
+            raise Exception("TIPS: no data for M,I = %d,%d." % key)
+        rows.append(t["q"][key])
+    B = np.stack(rows) if rows else np.zeros((0, npt))
+    I1 = np.searchsorted(A[1:], T, side="left") + 2
+    three = (I1 < 3) | (I1 == npt)
+    J = np.where(I1 < 3, 2, np.where(I1 == npt, npt - 1, I1 - 1))
+    idx = np.stack([J - 2, J - 1, J, np.minimum(J + 1, npt - 1)])      # [4][nT]; the 4th node unused where `three`
+    An = A[idx]                                                         # [4][nT]
+    Bn = B[:, idx]                                                      # [nS][4][nT]
+    out = np.zeros((B.shape[0], T.size))
+    if not three.any():  # every temperature inside the table (the normal case): plain 4-point form, distinct nodes
+        dT = [T - An[m] for m in range(4)]
+        for j in range(4):
+            num = 1.0
+            den = 1.0
+            for m in range(4):
+                if m != j:
+                    num = num * dT[m]
+                    den = den * (An[j] - An[m])
+            out = out + (num / den) * Bn[:, j, :]
+        return out
+    for j in range(4):
+        num = np.ones(T.size)
+        den = np.ones(T.size)
+        for m in range(4):
+            if m == j:
+                continue
+            use = ~three if m == 3 else np.ones(T.size, dtype=bool)
+            d = An[j] - An[m]
+            d = np.where(d != 0.0, d, 0.0001)
+            num = np.where(use, num * (T - An[m]), num)
+            den = np.where(use, den * d, den)
+        term = (num / den) * Bn[:, j, :]
+        out = out + (np.where(three, 0.0, term) if j == 3 else term)
+    return out
+
+
 def abundance(M, I):
     """Natural abundance, misc/hapi.py:5088-5103."""
     try:

@@ -225,6 +225,25 @@ def test_species_factors_skip_unselected_species():
         engine.species_factors(species, np.array([60.0]), weight=np.ones((3, 1)))
 
 
+def test_vectorised_tips_is_bit_identical_to_the_scalar_routine():
+    """tips.partition_sums (one NumPy pass per atmosphere, inside bench.py's timed step) == tips.partition_sum (the
+    statement-by-statement restatement of AtoB, misc/hapi.py:5311-5388, pinned by golden G3) to the last bit, including
+    the 3-point branches at both ends of the table and the 70 / 3000 K limits."""
+    from radtxfr_amd import synthetic, tips
+    rng = np.random.default_rng(5)
+    species = [(1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (2, 0)]
+    T = np.concatenate([synthetic.c3_atmosphere(32)["Ts"], [70.0, 84.9, 85.0, 85.1, 109.99, 110.0, 296.0, 2985.0, 2990.0, 3000.0],
+                        rng.uniform(70.0, 3000.0, 300)])
+    want = np.array([[tips.partition_sum(m, i, t) for t in T] for m, i in species])
+    assert np.array_equal(tips.partition_sums(species, T), want)
+    mid = rng.uniform(120.0, 2900.0, 64)  # fast path: every temperature inside the table
+    assert np.array_equal(tips.partition_sums(species, mid), np.array([[tips.partition_sum(m, i, t) for t in mid] for m, i in species]))
+    with pytest.raises(Exception):
+        tips.partition_sums(species, np.array([250.0, 69.9]))
+    with pytest.raises(Exception):
+        tips.partition_sums([(99, 1)], np.array([250.0]))
+
+
 def test_device_table_signature_covers_every_column():
     """hapi._device_table's cache key is a content fingerprint of all uploaded columns: editing sw (or any other
     column) in place, or swapping two rows, changes it (id(nu) + row count alone went stale)."""

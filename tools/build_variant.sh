@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/build/$NAME"
 cd "$ROOT/radtxfr_amd/csrc"
 for f in rtx_lines rtx_voigt rtx_voigt_scatter rtx_sdvoigt rtx_tud rtx_radiance rtx_resample; do
-  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DRTX_VOIGT_P=4 $EXTRA -Wno-unused-function -c $f.hip -o "$ROOT/build/$NAME/$f.o" &
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $EXTRA -Wno-unused-function -c $f.hip -o "$ROOT/build/$NAME/$f.o" &
 done
 wait
 hipcc -shared --offload-arch=gfx950 -o "$ROOT/build/$NAME.so" "$ROOT"/build/$NAME/*.o

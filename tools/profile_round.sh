@@ -13,8 +13,12 @@ ARGS="--steps 10 --warmup 3"
 timeout -k 10 300 python3 bench.py $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline > "$OUT/bench_prof.json" 2> "$OUT/trace.err" || exit 2
-for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES" "busy:SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES" "busy:SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" "trans:SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$name" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$name.err" || exit 3
 done
+cd "$ROOT"
+# thin-column TUD timing (tools/time_c3.py --mf-scale 1e-3) and the per-step host overhead
+timeout -k 10 200 python3 tools/time_c3.py --reps 5 --mf-scale 1e-3 > "$OUT/time_c3_thin.txt" 2>&1 || exit 4
+timeout -k 10 200 python3 tools/time_overhead.py > "$OUT/time_overhead.txt" 2>&1 || exit 5
 echo done

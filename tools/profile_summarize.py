@@ -60,5 +60,22 @@ if hit and "FETCH_SIZE" in per[hit[0]] and "WRITE_SIZE" in per[hit[0]]:
     with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
+if hit and "SQ_INSTS_VALU" in per[hit[0]]:
+    c = per[hit[0]]
+    avg_ns = None
+    for r in csv.DictReader(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))):
+        if dom in r["Name"]:
+            avg_ns = float(r["AverageNs"])
+    out = {"source": f"profiles/{tag}_pmc_counters.txt (rocprofv3 --pmc, separate passes; per-launch averages)",
+           "workload": "C3 n_gpus=1", "kernel": hit[0],
+           "sq_insts_valu": c["SQ_INSTS_VALU"], "sq_insts_valu_trans_f32": c.get("SQ_INSTS_VALU_TRANS_F32"),
+           "sq_insts_salu": c.get("SQ_INSTS_SALU"), "sq_insts_lds": c.get("SQ_INSTS_LDS"), "sq_insts_smem": c.get("SQ_INSTS_SMEM"),
+           "sq_waves": c.get("SQ_WAVES"), "ms_per_launch": avg_ns / 1e6 if avg_ns else None}
+    with open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+for extra in ("rehearsal_gloo2.json", "time_c3_thin.txt", "time_overhead.txt"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read()[:1500])
 print(open(os.path.join(dst, f"{tag}_pmc_counters.txt")).read())
