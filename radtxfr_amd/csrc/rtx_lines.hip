@@ -340,8 +340,10 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       if (gic > M) gic = M;
       a.ic[l] = sat_local(gic - g.offset, g.n);
     }
-    if (hi > lo) {
-      // window half-width in grid points, measured from the unshifted centre, with margin
+    if (!dropped && ghi > glo) {
+      // window half-width in grid points, measured from the unshifted centre, with margin. Taken over every live line
+      // whose window meets the FULL axis, not only this shard: the per-tile candidate ranges -- hence the order of the
+      // fp32 sums -- then do not depend on where a shard is cut (tile-aligned shards reproduce the full grid's bits)
       double hw = ceil(W / g.step) + 2.0;
       my_hw = hw > 1.0e9 ? 1000000000 : (int)hw;
     }

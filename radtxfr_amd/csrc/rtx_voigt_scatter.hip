@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #define CHEB_T_OFF CHEB_T_OFF_20
 #define CHEB_T_M1 CHEB_T_M1_20
 #endif
-__global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
+__global__ __launch_bounds__(256) void voigt_nodal_v1_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
   __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
@@ -616,6 +616,274 @@ __global__ __launch_bounds__(256) void voigt_nodal_kernel(ScArgs a) {
   }
 }
 
+
+// ---- main pass, second formulation (round 2): classify with lane = candidate line ------------------------------------
+// The first nodal kernel took its candidates 8 at a time with lane = (line, node): record loads, row geometry and row
+// masks were repeated by the 8 node lanes of every line, for every candidate -- a third of which never reach the
+// tile -- and the three levels were interleaved chunk by chunk behind masks and a ring. Here each wave first classifies
+// 64 candidates at once (lane = line: one record load, one row_geom per line, 64 lines per instruction), then serves
+// each level DENSELY:
+//   tile level / row level   the member lanes' ids are compacted with one ds_permute; groups of 8 members are evaluated
+//                            with lane = (member, node), the members' record fields fetched lane-to-lane with
+//                            ds_bpermute (no LDS storage, no second trip to memory);
+//   point by point           member lanes write the same 64-byte LDS entries as before and the wave drains them.
+// Candidates are dealt to the 4 waves in table order modulo 4, so each wave sees the same mix of far / edge / centre
+// lines. Evaluation arithmetic, masks, entry layout, drain and the two interpolation stages are those of the first
+// kernel; only the order of the fp32 sums changes.
+#ifndef RTX_SC_WAVES
+#define RTX_SC_WAVES 6
+#endif
+__global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a) {
+  constexpr int ROWS = RTX_SC_ROWS;
+  constexpr int TILE = 64 * ROWS;
+  __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
+  __shared__ float4 s_ent[4][SC_ENT_CAP][4];
+  __shared__ float s_nodsum[RTX_SC_ROWS][CHEB_N];
+  // after the last drain the entry lists are dead: wave w keeps its tile-level sums in the first 128 B of its list and
+  // its row-level sums [ROWS][8] behind them
+  static_assert(CHEB_T_N * 4 + RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "aliases fit in one wave's entry list");
+
+  const int b = blockIdx.x;
+  const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
+  if (tile >= a.n_tiles) return;
+  const int k = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const long long n = a.g.n;
+  const int ia = tile * TILE;
+  const int ib = (int)((long long)ia + TILE < n ? (long long)ia + TILE : n);
+  const int nt = ib - ia;
+  const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
+  const LineRec64* __restrict__ rec64 = a.rec64 + (size_t)k * (size_t)a.n_lines;
+  const int2 rng = a.ranges[(size_t)k * a.n_tiles + tile];
+  float* __restrict__ acc = s_acc[wave];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r * 64 + lane] = 0.f;
+  const float lanef = (float)lane;
+  bool touched = false;
+
+  // node evaluations: lane = (member l of the group, node j)
+  const int l = lane >> 3, j = lane & 7;
+  const float off_j = CHEB_OFF[j];
+  float nod[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) nod[r] = 0.f;
+  float nodT[SC_TPL], offT[SC_TPL];
+#pragma unroll
+  for (int i = 0; i < SC_TPL; ++i) {
+    nodT[i] = 0.f;
+    offT[i] = SC_TILE_LEVEL ? CHEB_T_OFF[j + 8 * i] : 0.f;
+  }
+  int n_ent = 0;  // wave-uniform
+  float4(*__restrict__ ent)[4] = s_ent[wave];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  auto pull = [](int src_lane, float v) -> float {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+  };
+
+  auto drain = [&]() {
+    for (int e = 0; e < n_ent; ++e) {
+      const float4 e0 = ent[e][0], e1 = ent[e][1], e2 = ent[e][2], e3 = ent[e][3];
+      LineRec q;
+      q.a = e0.x; q.c = e0.y; q.b1 = e0.z; q.b0 = e0.w;
+      q.Ay = e1.x; q.Ay0 = e1.y; q.y = e1.z; q.A = e1.w;
+      const float u0 = e2.x + lanef, ulo = e2.y, uhi = e2.z, zw_f = e2.w;
+      unsigned m_pp = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.x));
+      unsigned m_bd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.y));
+      const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(e3.z));
+      // far-wing rows, point by point, lanes outside the window masked (interior rows: mask all-true)
+      if (RTX_SC_ABLATE & 4) m_pp = 0u;
+      while (m_pp) {
+        const int r = __builtin_ctz(m_pp);
+        m_pp &= m_pp - 1u;
+        float* p = acc + r * 64 + lane;
+        const float u = u0 + (float)(64 * r);
+        float x0, n0, d0;
+        farwing(u, q, x0, n0, d0);
+        n0 = (u >= ulo && u < uhi) ? n0 : 0.f;
+        p[0] = fmaf(n0, d0, p[0]);
+      }
+      if (RTX_SC_ABLATE & 1) m_bd = 0u;
+      const bool small_y = q.y < 1.0f;
+      while (m_bd) {
+        const int r = __builtin_ctz(m_bd);
+        m_bd &= m_bd - 1u;
+        float* p = acc + r * 64 + lane;
+        float num, rden;
+        band_row<false>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
+        p[0] = fmaf(num, rden, p[0]);
+      }
+    }
+    n_ent = 0;
+  };
+
+  // 256 candidates per round: wave w, lane i takes candidate rng.x + w + 4 i (+ 256 per round)
+  for (int base = rng.x + wave; base < rng.y; base += 256) {
+    const int slot = base + 4 * lane;
+    const bool valid = slot < rng.y;
+    const float4* __restrict__ pr = reinterpret_cast<const float4*>(rec + (valid ? slot : rng.y - 1));
+    const float4 f0 = pr[0];  // a c b1 b0
+    const float4 f1 = pr[1];  // Ay Ay0 y A
+    const float4 f2 = pr[2];  // i0 lo hi zw (int bits)
+    const int qi0 = __float_as_int(f2.x), qlo = __float_as_int(f2.y), qhi = __float_as_int(f2.z), qzw = __float_as_int(f2.w);
+    const bool reach = valid && qhi > ia && qlo < ib;
+    const RowGeom g = row_geom(qi0, qlo, qhi, qzw, ia, nt);
+    auto bits = [](int lo, int hi) -> unsigned {  // rows [lo, hi), 0 <= lo, hi <= ROWS
+      return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    };
+    const unsigned m_reach = reach ? bits(g.r_lo, g.r_hi) : 0u;
+    const unsigned m_in = reach ? bits(g.c0, g.c1) : 0u;
+    const unsigned m_near = bits(g.n0 > 0 ? g.n0 : 0, (g.n1 < ROWS - 1 ? g.n1 : ROWS - 1) + 1);
+    const unsigned m_band = bits(g.z0, g.z1 + 1);
+    // tile level: the window covers the whole tile and the near zone (centre +- SC_NEAR rows, band) lies outside it
+    const bool is_t = SC_TILE_LEVEL && !(RTX_SC_ABLATE & 2) && reach && qlo <= ia && qhi - ia >= nt && (g.n1 < 0 || g.n0 >= ROWS);
+    const unsigned m_far = (is_t || (RTX_SC_ABLATE & 2)) ? 0u : (m_in & ~m_near);   // smooth: Chebyshev nodes of the rows
+    const unsigned m_bd = m_reach & m_band;                                        // band rows
+    const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;      // near-zone rows and window edges
+    const float ub = (float)(ia - qi0);  // integer-valued
+
+    // ---- point-by-point rows: 64-byte entries, drained by the whole wave ---------------------------------------
+    {
+      bool emit = !(RTX_SC_ABLATE & 8) && (m_pp | m_bd) != 0u;
+      unsigned long long eb = __ballot(emit);
+      while (eb) {
+        const int room = SC_ENT_CAP - n_ent;
+        const int r = __popcll(eb & lt);
+        if (emit && r < room) {
+          float4* d = ent[n_ent + r];
+          d[0] = f0;
+          d[1] = f1;
+          d[2] = make_float4(ub, (float)(qlo - qi0), (float)(qhi - qi0), qzw > 0 ? (float)qzw : -1.0f);
+          d[3] = make_float4(__int_as_float((int)m_pp), __int_as_float((int)m_bd), __int_as_float(slot), 0.f);
+          emit = false;
+        }
+        const int cnt = __popcll(eb);
+        n_ent += cnt < room ? cnt : room;
+        if (n_ent == SC_ENT_CAP) drain();
+        eb = __ballot(emit);
+      }
+    }
+    // ---- tile level: 32 nodes over the tile, 8 member lines per pass -------------------------------------------
+    if (SC_TILE_LEVEL) {
+      const unsigned long long tb = __ballot(is_t);
+      if (tb) {
+        const int nT = __popcll(tb);
+        // member of rank r sends its lane id to lane r; the others all write to lane 63, which no member targets
+        const int src = __builtin_amdgcn_ds_permute((is_t ? __popcll(tb & lt) : 63) << 2, lane);
+        for (int g0 = 0; g0 < nT; g0 += 8) {
+          const int e = g0 + l;
+          const int sl = __builtin_amdgcn_ds_bpermute(e << 2, src);
+          const int okm = e < nT ? -1 : 0;
+          const float qa = pull(sl, f0.x), qc = pull(sl, f0.y), qb1 = pull(sl, f0.z), qb0 = pull(sl, f0.w);
+          const float qAy = pull(sl, f1.x), qAy0 = pull(sl, f1.y), qub = pull(sl, ub);
+#pragma unroll
+          for (int i = 0; i < SC_TPL; ++i) {
+            const float x = fmaf(qub, qa, fmaf(offT[i], qa, qc));
+            const float xx = x * x;
+            float num = fmaf(xx, qAy, qAy0);
+            const float rden = __builtin_amdgcn_rcpf(fmaf(xx + qb1, xx, qb0));
+            num = __int_as_float(__float_as_int(num) & okm);
+            nodT[i] = fmaf(num, rden, nodT[i]);
+          }
+        }
+      }
+    }
+    // ---- row level: 8 nodes per row, rows by mask, 8 member lines per pass -------------------------------------
+    {
+      const bool is_r = m_far != 0u;
+      const unsigned long long rb = __ballot(is_r);
+      if (rb) {
+        const int nR = __popcll(rb);
+        const int src = __builtin_amdgcn_ds_permute((is_r ? __popcll(rb & lt) : 63) << 2, lane);
+        for (int g0 = 0; g0 < nR; g0 += 8) {
+          const int e = g0 + l;
+          const int sl = __builtin_amdgcn_ds_bpermute(e << 2, src);
+          const float qa = pull(sl, f0.x), qc = pull(sl, f0.y), qb1 = pull(sl, f0.z), qb0 = pull(sl, f0.w);
+          const float qAy = pull(sl, f1.x), qAy0 = pull(sl, f1.y), qub = pull(sl, ub);
+          int mf = __builtin_amdgcn_ds_bpermute(sl << 2, (int)m_far);
+          mf = e < nR ? mf : 0;
+          const float cj = fmaf(off_j, qa, qc);  // x at (row start + node offset) relative to u = 0
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const float x = fmaf(qub + (float)(64 * r), qa, cj);
+            const float xx = x * x;
+            float num = fmaf(xx, qAy, qAy0);
+            const float rden = __builtin_amdgcn_rcpf(fmaf(xx + qb1, xx, qb0));
+            num = __int_as_float(__float_as_int(num) & __builtin_amdgcn_sbfe(mf, r, 1));
+            nod[r] = fmaf(num, rden, nod[r]);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 4 rows in flight: bounds the registers the scheduler takes
+          }
+        }
+      }
+    }
+  }
+  drain();
+
+  // sum the 8 member slots of each node (lanes l = 0..7 of equal j), one copy per wave
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    float v = nod[r];
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[CHEB_T_N + r * CHEB_N + lane] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < SC_TPL; ++i) {
+    float v = nodT[i];
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (SC_TILE_LEVEL && lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[lane + 8 * i] = v;
+  }
+  __syncthreads();
+  const float* nT0 = reinterpret_cast<const float*>(&s_ent[0][0][0]);
+  const float* nT1 = reinterpret_cast<const float*>(&s_ent[1][0][0]);
+  const float* nT2 = reinterpret_cast<const float*>(&s_ent[2][0][0]);
+  const float* nT3 = reinterpret_cast<const float*>(&s_ent[3][0][0]);
+  // stage 1: thread (r, jj) gathers the four waves' row-level sums and carries the tile-level sums to its row node
+  if (threadIdx.x < ROWS * CHEB_N) {
+    const int o = CHEB_T_N + threadIdx.x;  // = CHEB_T_N + r * CHEB_N + jj
+    float v = (nT0[o] + nT1[o]) + (nT2[o] + nT3[o]);
+    if (SC_TILE_LEVEL) {
+      const float4* __restrict__ m1 = reinterpret_cast<const float4*>(CHEB_T_M1[threadIdx.x]);
+      float f = 0.f;
+#pragma unroll
+      for (int m = 0; m < CHEB_T_N / 4; ++m) {
+        const float4 w = m1[m];
+        const int c = 4 * m;
+        f = fmaf(w.x, (nT0[c] + nT1[c]) + (nT2[c] + nT3[c]), f);
+        f = fmaf(w.y, (nT0[c + 1] + nT1[c + 1]) + (nT2[c + 1] + nT3[c + 1]), f);
+        f = fmaf(w.z, (nT0[c + 2] + nT1[c + 2]) + (nT2[c + 2] + nT3[c + 2]), f);
+        f = fmaf(w.w, (nT0[c + 3] + nT1[c + 3]) + (nT2[c + 3] + nT3[c + 3]), f);
+      }
+      v += f;
+    }
+    s_nodsum[threadIdx.x >> 3][threadIdx.x & 7] = v;
+  }
+  __syncthreads();
+  // stage 2: row nodes -> grid points, plus the four point-by-point copies; coalesced stores
+  {
+    float wl[CHEB_N];
+#pragma unroll
+    for (int jj = 0; jj < CHEB_N; ++jj) wl[jj] = CHEB_W[lane][jj];
+#pragma unroll 4
+    for (int r = wave; r < ROWS; r += 4) {
+      const int t = r * 64 + lane;
+      const long long i = (long long)ia + t;
+      float f = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < CHEB_N; ++jj) f = fmaf(wl[jj], s_nodsum[r][jj], f);
+      const float v = ((s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t])) + f;
+      if (i < (long long)ib) {
+        const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
+        if (a.out32) a.out32[o] = v;
+        if (a.out64) a.out64[o] = (double)v * a.inv_scale;
+      }
+    }
+  }
+}
+
 extern "C" int rtx_voigt_scatter_tile_points(void) { return 64 * RTX_SC_ROWS; }
 
 int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64, int64_t ld,
@@ -648,7 +916,8 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   // RADTXFR_DEBUG_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, to time the kernel at reduced occupancy
   static int lds_pad = -1;
   if (lds_pad < 0) { const char* e = getenv("RADTXFR_DEBUG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
-  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
+  if (nodal == 2) hipLaunchKernelGGL(voigt_nodal_v1_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
+  else if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
   else hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
 #if RTX_SC_STAMP
