@@ -62,11 +62,11 @@ static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_la
 }
 
 // RADTXFR_VOIGT_KERNEL=scatter selects the point-by-point cross-check kernel instead of the default nodal one.
-static int voigt_kernel_choice() {  // 0 nodal, 1 scatter, 2 first nodal kernel (A/B during round 2)
+static int voigt_kernel_choice() {  // 0 nodal, 1 scatter
   static int cached = -1;
   if (cached < 0) {
     const char* e = getenv("RADTXFR_VOIGT_KERNEL");
-    cached = (e && strcmp(e, "scatter") == 0) ? 1 : (e && strcmp(e, "nodal1") == 0) ? 2 : 0;
+    cached = (e && strcmp(e, "scatter") == 0) ? 1 : 0;
   }
   return cached;
 }
@@ -85,5 +85,5 @@ extern "C" int rtx_voigt_sum(const rtx_prep* P, const rtx_grid* grid, int n_laye
     if (out_f64) RTX_HIP(hipMemset2DAsync(out_f64, ld * sizeof(double), 0, grid->n * sizeof(double), n_layers, st));
     return 0;
   }
-  return rtx_voigt_sum_scatter(P, grid, n_layers, out_f32, out_f64, ld, st, launch_tile_ranges, voigt_kernel_choice() == 0 ? 1 : voigt_kernel_choice() == 2 ? 2 : 0);
+  return rtx_voigt_sum_scatter(P, grid, n_layers, out_f32, out_f64, ld, st, launch_tile_ranges, voigt_kernel_choice() == 0);
 }

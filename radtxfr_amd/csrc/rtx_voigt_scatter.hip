@@ -328,310 +328,35 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
   store_tile<CORE64, false>(a, s_acc, nullptr, k, ia, ib, wave, lane);
 }
 
-// ---- main pass, far rows at Chebyshev nodes -------------------------------------------------------------
-// Per-wave list of the lines that need point-by-point rows in this tile. The classification lanes write a 64-B
-// entry (record fields, window in u, row masks); the consumer reads it back with broadcast LDS reads, so a line
-// costs no scalar load, no scalar geometry and its constants reach the VALU as (wave-uniform) vector operands.
-#ifndef SC_ENT_CAP
-#define SC_ENT_CAP 16
-#endif
-// tile level (32 nodes over the whole tile) needs the generated tables to match the tile length
-#ifndef SC_TILE_LEVEL
-#define SC_TILE_LEVEL (RTX_SC_ROWS == 12 || RTX_SC_ROWS == 16 || RTX_SC_ROWS == 20 || RTX_SC_ROWS == 24)
-#endif
-#define SC_TPL (CHEB_T_N / 8)
-#define SC_CAT_(a_, b_) a_##b_
-#define SC_CAT(a_, b_) SC_CAT_(a_, b_)
-#if SC_TILE_LEVEL
-#define CHEB_T_OFF SC_CAT(CHEB_T_OFF_, RTX_SC_ROWS)
-#define CHEB_T_M1 SC_CAT(CHEB_T_M1_, RTX_SC_ROWS)
-#else
-#define CHEB_T_OFF CHEB_T_OFF_20
-#define CHEB_T_M1 CHEB_T_M1_20
-#endif
-__global__ __launch_bounds__(256) void voigt_nodal_v1_kernel(ScArgs a) {
-  constexpr int ROWS = RTX_SC_ROWS;
-  constexpr int TILE = 64 * ROWS;
-  __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
-  __shared__ float4 s_ent[4][SC_ENT_CAP][4];
-  __shared__ float4 s_rowl[4][16][2];           // per-wave ring of lines with row-level far rows: (a c b1 b0) (Ay Ay0 ub mask)
-  // after the last drain the entry lists are dead: wave w keeps its tile-level sums in the first 128 B of its list,
-  // and the combined row-node sums [ROWS][8] live behind wave 0's
-  // [0,128) B of its entry list, its row-level sums [ROWS][8] behind them; the combined row-node sums live in the rings
-  static_assert(CHEB_T_N * 4 + RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "aliases fit in one wave's entry list");
-  static_assert(RTX_SC_ROWS * CHEB_N * 4 <= 4 * 16 * 2 * 16, "combined sums fit in the rings");
-
-  const int b = blockIdx.x;
-  const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
-  if (tile >= a.n_tiles) return;
-  const int k = blockIdx.y;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const long long n = a.g.n;
-  const int ia = tile * TILE;
-  const int ib = (int)((long long)ia + TILE < n ? (long long)ia + TILE : n);
-  const int nt = ib - ia;
-  const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
-  const LineRec64* __restrict__ rec64 = a.rec64 + (size_t)k * (size_t)a.n_lines;
-  const int2 rng = a.ranges[(size_t)k * a.n_tiles + tile];
-  float* __restrict__ acc = s_acc[wave];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) acc[r * 64 + lane] = 0.f;
-  const float lanef = (float)lane;
-  bool touched = false;
-  long long t_ph[SC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long t_prev = RTX_SC_STAMP ? (long long)clock64() : 0;
-  const long long t_begin = t_prev;
-
-  // lane = (line l of the chunk, node j)
-  const int l = lane >> 3, j = lane & 7;
-  const float off_j = CHEB_OFF[j];
-  float nod[ROWS];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) nod[r] = 0.f;
-  // tile level: lane (l, j) evaluates tile nodes j, j + 8, j + 16, j + 24 of line l
-  float nodT[SC_TPL], offT[SC_TPL];
-#pragma unroll
-  for (int i = 0; i < SC_TPL; ++i) {
-    nodT[i] = 0.f;
-    offT[i] = SC_TILE_LEVEL ? CHEB_T_OFF[j + 8 * i] : 0.f;
-  }
-  int n_ent = 0;  // wave-uniform
-  int n_row_head = 0, n_row_tail = 0;  // wave-uniform ring indices
-  float4(*__restrict__ rowl)[2] = s_rowl[wave];
-  auto far_rows = [&](const float4 fa, const float4 fb) {  // lane (l, j): node j of the rows of ring entry l
-    const float cj = fmaf(off_j, fa.x, fa.y);  // x at (row start + node offset) relative to u = 0
-    const int mf = __float_as_int(fb.w);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const float x = fmaf(fb.z + (float)(64 * r), fa.x, cj);
-      const float xx = x * x;
-      float num = fmaf(xx, fb.x, fb.y);
-      const float rden = __builtin_amdgcn_rcpf(fmaf(xx + fa.z, xx, fa.w));
-      num = __int_as_float(__float_as_int(num) & __builtin_amdgcn_sbfe(mf, r, 1));
-      nod[r] = fmaf(num, rden, nod[r]);
-    }
-  };
-  float4(*__restrict__ ent)[4] = s_ent[wave];
-
-  auto drain = [&]() {
-    for (int e = 0; e < n_ent; ++e) {
-      const float4 e0 = ent[e][0], e1 = ent[e][1], e2 = ent[e][2], e3 = ent[e][3];
-      LineRec q;
-      q.a = e0.x; q.c = e0.y; q.b1 = e0.z; q.b0 = e0.w;
-      q.Ay = e1.x; q.Ay0 = e1.y; q.y = e1.z; q.A = e1.w;
-      const float u0 = e2.x + lanef, ulo = e2.y, uhi = e2.z, zw_f = e2.w;
-      unsigned m_pp = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.x));
-      unsigned m_bd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.y));
-      const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(e3.z));
-      STAMP(3);  // entry read
-      // far-wing rows, point by point, lanes outside the window masked (interior rows: mask all-true)
-      if (RTX_SC_ABLATE & 4) m_pp = 0u;
-      while (m_pp) {
-        const int r = __builtin_ctz(m_pp);
-        m_pp &= m_pp - 1u;
-        float* p = acc + r * 64 + lane;
-        const float u = u0 + (float)(64 * r);
-        float x0, n0, d0;
-        farwing(u, q, x0, n0, d0);
-        n0 = (u >= ulo && u < uhi) ? n0 : 0.f;
-        p[0] = fmaf(n0, d0, p[0]);
-      }
-      STAMP(4);  // pp rows
-      if (RTX_SC_ABLATE & 1) m_bd = 0u;
-      const bool small_y = q.y < 1.0f;
-      while (m_bd) {
-        const int r = __builtin_ctz(m_bd);
-        m_bd &= m_bd - 1u;
-        float* p = acc + r * 64 + lane;
-        float num, rden;
-        band_row<false>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
-        p[0] = fmaf(num, rden, p[0]);
-      }
-      STAMP(5);  // band rows
-    }
-    n_ent = 0;
-  };
-
-  // chunks of 8 candidate lines, dealt round-robin to the 4 waves in table order
-  for (int c_base = rng.x + 8 * wave; c_base < rng.y; c_base += 32) {
-    const int slot = c_base + l;
-    const bool valid = slot < rng.y;
-    const float4* __restrict__ pr = reinterpret_cast<const float4*>(rec + (valid ? slot : rng.y - 1));
-    const float4 f0 = pr[0];  // a c b1 b0
-    const float4 f1 = pr[1];  // Ay Ay0 y A
-    const float4 f2 = pr[2];  // i0 lo hi zw (int bits)
-    const int qi0 = __float_as_int(f2.x), qlo = __float_as_int(f2.y), qhi = __float_as_int(f2.z), qzw = __float_as_int(f2.w);
-    const bool reach = valid && qhi > ia && qlo < ib;
-    const RowGeom g = row_geom(qi0, qlo, qhi, qzw, ia, nt);
-    // row masks: reached / wholly inside the window / near zone / band
-    auto bits = [](int lo, int hi) -> unsigned {  // rows [lo, hi), 0 <= lo, hi <= ROWS
-      return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-    };
-    const unsigned m_reach = reach ? bits(g.r_lo, g.r_hi) : 0u;
-    const unsigned m_in = reach ? bits(g.c0, g.c1) : 0u;
-    const unsigned m_near = bits(g.n0 > 0 ? g.n0 : 0, (g.n1 < ROWS - 1 ? g.n1 : ROWS - 1) + 1);
-    const unsigned m_band = bits(g.z0, g.z1 + 1);
-    // tile level: the window covers the whole tile and the near zone (centre +- SC_NEAR rows, band) lies outside it
-    const bool is_t = SC_TILE_LEVEL && reach && qlo <= ia && qhi - ia >= nt && (g.n1 < 0 || g.n0 >= ROWS);
-    const unsigned m_far = is_t ? 0u : (m_in & ~m_near);                     // smooth: Chebyshev nodes of the rows
-    const unsigned m_bd = m_reach & m_band;                                  // band rows
-    const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;  // near-zone rows and window edges
-    if (RTX_SC_STAMP && __ballot(m_pp == 0xffffffffu)) t_ph[7] += 1;  // (forces the masks, i.e. the record loads, before the stamp)
-    STAMP(0);  // record loads + geometry
-
-    const float ub = (float)(ia - qi0);  // integer-valued
-    if (SC_TILE_LEVEL && !(RTX_SC_ABLATE & 2) && __ballot(is_t)) {
-      const int t_mask = is_t ? -1 : 0;
-#pragma unroll
-      for (int i = 0; i < SC_TPL; ++i) {
-        const float x = fmaf(ub, f0.x, fmaf(offT[i], f0.x, f0.y));
-        const float xx = x * x;
-        float num = fmaf(xx, f1.x, f1.y);
-        const float rden = __builtin_amdgcn_rcpf(fmaf(xx + f0.z, xx, f0.w));
-        num = __int_as_float(__float_as_int(num) & t_mask);
-        nodT[i] = fmaf(num, rden, nodT[i]);
-      }
-    }
-    // lines with row-level far rows go through a per-wave ring so that the 20-row evaluation always runs on 8 such
-    // lines at once (edge lines are scattered through the table order: evaluated in place they would drag nearly
-    // every step through the row loop for one or two useful lanes)
-    {
-      const bool push = !(RTX_SC_ABLATE & 2) && j == 0 && m_far != 0u;
-      const unsigned long long pb = __ballot(push);
-      if (pb) {
-        if (push) {
-          float4* d = rowl[(n_row_tail + __popcll(pb & ((1ull << lane) - 1ull))) & 15];
-          d[0] = f0;
-          d[1] = make_float4(f1.x, f1.y, ub, __int_as_float((int)m_far));
-        }
-        n_row_tail += __popcll(pb);
-        if (n_row_tail - n_row_head >= 8) {
-          far_rows(rowl[(n_row_head + l) & 15][0], rowl[(n_row_head + l) & 15][1]);
-          n_row_head += 8;
-        }
-      }
-    }
-    STAMP(1);  // far rows
-    const bool emit = !(RTX_SC_ABLATE & 8) && j == 0 && (m_pp | m_bd) != 0u;
-    const unsigned long long eb = __ballot(emit);
-    if (eb) {
-      if (emit) {
-        float4* d = ent[n_ent + __popcll(eb & ((1ull << lane) - 1ull))];
-        d[0] = f0;
-        d[1] = f1;
-        d[2] = make_float4((float)(ia - qi0), (float)(qlo - qi0), (float)(qhi - qi0), qzw > 0 ? (float)qzw : -1.0f);
-        d[3] = make_float4(__int_as_float((int)m_pp), __int_as_float((int)m_bd), __int_as_float(slot), 0.f);
-      }
-      n_ent += __popcll(eb);
-      STAMP(2);  // emission
-      if (n_ent > SC_ENT_CAP - 8) drain();
-    }
-  }
-  drain();
-  if (n_row_tail != n_row_head) {  // the last, partial batch: empty slots get a zero mask
-    float4 fa = rowl[(n_row_head + l) & 15][0], fb = rowl[(n_row_head + l) & 15][1];
-    if (n_row_head + l >= n_row_tail) {  // never written: benign operands (den = 1), zero mask
-      fa = make_float4(0.f, 0.f, 0.f, 1.f);
-      fb = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    far_rows(fa, fb);
-  }
-
-  // sum the 8 line slots of each node (lanes l = 0..7 of equal j), one copy per wave
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    float v = nod[r];
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[CHEB_T_N + r * CHEB_N + lane] = v;
-  }
-#pragma unroll
-  for (int i = 0; i < SC_TPL; ++i) {
-    float v = nodT[i];
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (SC_TILE_LEVEL && lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[lane + 8 * i] = v;
-  }
-  STAMP(2);
-  __syncthreads();
-  STAMP(6);  // barrier
-  const float* nT0 = reinterpret_cast<const float*>(&s_ent[0][0][0]);
-  const float* nT1 = reinterpret_cast<const float*>(&s_ent[1][0][0]);
-  const float* nT2 = reinterpret_cast<const float*>(&s_ent[2][0][0]);
-  const float* nT3 = reinterpret_cast<const float*>(&s_ent[3][0][0]);
-  float(*s_nodsum)[CHEB_N] = reinterpret_cast<float(*)[CHEB_N]>(&s_rowl[0][0][0]);
-  // stage 1: thread (r, jj) gathers the four waves' row-level sums and carries the tile-level sums to its row node
-  if (threadIdx.x < ROWS * CHEB_N) {
-    const int r = threadIdx.x >> 3, jj = threadIdx.x & 7;
-    const int o = CHEB_T_N + threadIdx.x;  // = CHEB_T_N + r * CHEB_N + jj
-    float v = (nT0[o] + nT1[o]) + (nT2[o] + nT3[o]);
-    if (SC_TILE_LEVEL) {
-      const float4* __restrict__ m1 = reinterpret_cast<const float4*>(CHEB_T_M1[threadIdx.x]);
-      float f = 0.f;
-#pragma unroll
-      for (int m = 0; m < CHEB_T_N / 4; ++m) {
-        const float4 w = m1[m];
-        const int c = 4 * m;
-        f = fmaf(w.x, (nT0[c] + nT1[c]) + (nT2[c] + nT3[c]), f);
-        f = fmaf(w.y, (nT0[c + 1] + nT1[c + 1]) + (nT2[c + 1] + nT3[c + 1]), f);
-        f = fmaf(w.z, (nT0[c + 2] + nT1[c + 2]) + (nT2[c + 2] + nT3[c + 2]), f);
-        f = fmaf(w.w, (nT0[c + 3] + nT1[c + 3]) + (nT2[c + 3] + nT3[c + 3]), f);
-      }
-      v += f;
-    }
-    s_nodsum[r][jj] = v;
-  }
-  __syncthreads();
-  // stage 2: row nodes -> grid points, plus the four point-by-point copies; coalesced stores
-  {
-    float wl[CHEB_N];
-#pragma unroll
-    for (int jj = 0; jj < CHEB_N; ++jj) wl[jj] = CHEB_W[lane][jj];
-#pragma unroll 4
-    for (int r = wave; r < ROWS; r += 4) {
-      const int t = r * 64 + lane;
-      const long long i = (long long)ia + t;
-      float f = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < CHEB_N; ++jj) f = fmaf(wl[jj], s_nodsum[r][jj], f);
-      const float v = ((s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t])) + f;
-      if (i < (long long)ib) {
-        const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
-        if (a.out32) a.out32[o] = v;
-        if (a.out64) a.out64[o] = (double)v * a.inv_scale;
-      }
-    }
-  }
-  if (RTX_SC_STAMP) {
-    t_ph[7] = (long long)clock64() - t_begin;  // lifetime
-    t_ph[6] = t_begin;                          // absolute start (replaces the barrier bucket in the dump)
-    t_ph[2] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(6164) << 32);  // HW_ID | XCC_ID << 32
-    if (lane == 0) {
-      unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * SC_NSTAMP;
-      for (int i = 0; i < SC_NSTAMP; ++i) o[i] = (unsigned long long)t_ph[i];
-    }
-  }
-}
-
-
-// ---- main pass, second formulation (round 2): classify with lane = candidate line ------------------------------------
-// The first nodal kernel took its candidates 8 at a time with lane = (line, node): record loads, row geometry and row
-// masks were repeated by the 8 node lanes of every line, for every candidate -- a third of which never reach the
-// tile -- and the three levels were interleaved chunk by chunk behind masks and a ring. Here each wave first classifies
-// 64 candidates at once (lane = line: one record load, one row_geom per line, 64 lines per instruction), then serves
-// each level DENSELY:
-//   tile level / row level   the member lanes' ids are compacted with one ds_permute; groups of 8 members are evaluated
-//                            with lane = (member, node), the members' record fields fetched lane-to-lane with
-//                            ds_bpermute (no LDS storage, no second trip to memory);
-//   point by point           member lanes write the same 64-byte LDS entries as before and the wave drains them.
-// Candidates are dealt to the 4 waves in table order modulo 4, so each wave sees the same mix of far / edge / centre
-// lines. Evaluation arithmetic, masks, entry layout, drain and the two interpolation stages are those of the first
-// kernel; only the order of the fp32 sums changes.
+// ---- main pass: far rows at Chebyshev nodes, near rows point by point --------------------------------------------------
+// A workgroup owns a tile of ROWS rows of 64 grid points of one layer. Every candidate line of the tile's range is
+// classified ONCE, with lane = candidate (one record load and one row_geom per line, 64 lines per instruction; the
+// candidates are dealt to the 4 waves in table order modulo 4, so each wave sees the same mix of far / edge / centre
+// lines), and then served by level:
+//   row level        rows wholly inside the line's window and outside its near zone (centre row +- SC_NEAR rows, widened
+//                    to the Weideman band): the line is the smooth far-wing rational there and is evaluated at the row's 8
+//                    Chebyshev nodes only. The member lanes' ids are compacted with one ds_permute; groups of 8 members
+//                    are evaluated with lane = (member, node), the members' record fields fetched lane-to-lane with
+//                    ds_bpermute (no LDS storage, no second trip to memory). Members whose window covers the whole tile
+//                    ("full": 40 % of them on C3) skip the per-row masks.
+//   point by point   near-zone rows, the <= 2 rows cut by a window edge, band rows: the member lanes write 64-byte LDS
+//                    entries (record fields, window in u, row masks) and the wave drains them, accumulating into its
+//                    own copy of the tile in LDS (plain read/add/write, no atomics, fixed order).
+// The nodal sums of all lines are carried to the 64 grid points of each row once per tile by the 64 x 8 Lagrange matrix
+// (interpolation is linear), fused with the fixed-order sum of the four point-by-point copies and the coalesced stores.
+//
+// Round-2 history (C3, prologue + line-sum): first nodal kernel (lane = (line, node) for classification too, a tile
+// level of 32 nodes, a ring for row-level lines) 2.84 ms -> lane = candidate classification + dense groups 2.58 -> tile
+// level dropped 2.44 (its 160 x 32 tile-nodes -> row-nodes matrix, read uncoalesced by 160 threads per tile, cost
+// 0.18 ms; evaluating those lines at row level costs less than that) -> this form. Measured slower: the point-by-point
+// members broadcast out of their lanes with v_readlane instead of LDS entries (2.78), two point-by-point rows in flight
+// (2.60), entries drained once per round with the records reloaded on overflow (2.69), tiles of 12 / 16 / 24 rows
+// (2.71 / 2.63 / 2.82).
 #ifndef RTX_SC_WAVES
 #define RTX_SC_WAVES 6
+#endif
+#ifndef SC_ENT_CAP
+#define SC_ENT_CAP 16  // point-by-point entries per wave (64 B each); 23 is the most that keeps 6 workgroups per CU in LDS
 #endif
 __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
@@ -639,9 +364,8 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
   __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
   __shared__ float4 s_ent[4][SC_ENT_CAP][4];
   __shared__ float s_nodsum[RTX_SC_ROWS][CHEB_N];
-  // after the last drain the entry lists are dead: wave w keeps its tile-level sums in the first 128 B of its list and
-  // its row-level sums [ROWS][8] behind them
-  static_assert(CHEB_T_N * 4 + RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "aliases fit in one wave's entry list");
+  // after the last drain the entry lists are dead: wave w keeps its row-level sums [ROWS][8] in its list
+  static_assert(RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "row sums fit in one wave's entry list");
 
   const int b = blockIdx.x;
   const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
@@ -668,12 +392,6 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
   float nod[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) nod[r] = 0.f;
-  float nodT[SC_TPL], offT[SC_TPL];
-#pragma unroll
-  for (int i = 0; i < SC_TPL; ++i) {
-    nodT[i] = 0.f;
-    offT[i] = SC_TILE_LEVEL ? CHEB_T_OFF[j + 8 * i] : 0.f;
-  }
   int n_ent = 0;  // wave-uniform
   float4(*__restrict__ ent)[4] = s_ent[wave];
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -735,12 +453,11 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
     const unsigned m_in = reach ? bits(g.c0, g.c1) : 0u;
     const unsigned m_near = bits(g.n0 > 0 ? g.n0 : 0, (g.n1 < ROWS - 1 ? g.n1 : ROWS - 1) + 1);
     const unsigned m_band = bits(g.z0, g.z1 + 1);
-    // tile level: the window covers the whole tile and the near zone (centre +- SC_NEAR rows, band) lies outside it
-    const bool is_t = SC_TILE_LEVEL && !(RTX_SC_ABLATE & 2) && reach && qlo <= ia && qhi - ia >= nt && (g.n1 < 0 || g.n0 >= ROWS);
-    const unsigned m_far = (is_t || (RTX_SC_ABLATE & 2)) ? 0u : (m_in & ~m_near);   // smooth: Chebyshev nodes of the rows
-    const unsigned m_bd = m_reach & m_band;                                        // band rows
-    const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;      // near-zone rows and window edges
+    const unsigned m_far = (RTX_SC_ABLATE & 2) ? 0u : (m_in & ~m_near);           // smooth: Chebyshev nodes of the rows
+    const unsigned m_bd = m_reach & m_band;                                       // band rows
+    const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;     // near-zone rows and window edges
     const float ub = (float)(ia - qi0);  // integer-valued
+    constexpr unsigned ALL_ROWS = (1u << ROWS) - 1u;
 
     // ---- point-by-point rows: 64-byte entries, drained by the whole wave ---------------------------------------
     {
@@ -763,55 +480,45 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
         eb = __ballot(emit);
       }
     }
-    // ---- tile level: 32 nodes over the tile, 8 member lines per pass -------------------------------------------
-    if (SC_TILE_LEVEL) {
-      const unsigned long long tb = __ballot(is_t);
-      if (tb) {
-        const int nT = __popcll(tb);
-        // member of rank r sends its lane id to lane r; the others all write to lane 63, which no member targets
-        const int src = __builtin_amdgcn_ds_permute((is_t ? __popcll(tb & lt) : 63) << 2, lane);
-        for (int g0 = 0; g0 < nT; g0 += 8) {
-          const int e = g0 + l;
-          const int sl = __builtin_amdgcn_ds_bpermute(e << 2, src);
-          const int okm = e < nT ? -1 : 0;
-          const float qa = pull(sl, f0.x), qc = pull(sl, f0.y), qb1 = pull(sl, f0.z), qb0 = pull(sl, f0.w);
-          const float qAy = pull(sl, f1.x), qAy0 = pull(sl, f1.y), qub = pull(sl, ub);
+    // ---- row level, 8 member lines per pass; x of node j in row r = x0 + r dx (one FMA per row) ----------------
+    // full members first (no masks), then the partial ones
 #pragma unroll
-          for (int i = 0; i < SC_TPL; ++i) {
-            const float x = fmaf(qub, qa, fmaf(offT[i], qa, qc));
-            const float xx = x * x;
-            float num = fmaf(xx, qAy, qAy0);
-            const float rden = __builtin_amdgcn_rcpf(fmaf(xx + qb1, xx, qb0));
-            num = __int_as_float(__float_as_int(num) & okm);
-            nodT[i] = fmaf(num, rden, nodT[i]);
-          }
-        }
-      }
-    }
-    // ---- row level: 8 nodes per row, rows by mask, 8 member lines per pass -------------------------------------
-    {
-      const bool is_r = m_far != 0u;
-      const unsigned long long rb = __ballot(is_r);
-      if (rb) {
-        const int nR = __popcll(rb);
-        const int src = __builtin_amdgcn_ds_permute((is_r ? __popcll(rb & lt) : 63) << 2, lane);
-        for (int g0 = 0; g0 < nR; g0 += 8) {
-          const int e = g0 + l;
-          const int sl = __builtin_amdgcn_ds_bpermute(e << 2, src);
-          const float qa = pull(sl, f0.x), qc = pull(sl, f0.y), qb1 = pull(sl, f0.z), qb0 = pull(sl, f0.w);
-          const float qAy = pull(sl, f1.x), qAy0 = pull(sl, f1.y), qub = pull(sl, ub);
-          int mf = __builtin_amdgcn_ds_bpermute(sl << 2, (int)m_far);
-          mf = e < nR ? mf : 0;
-          const float cj = fmaf(off_j, qa, qc);  // x at (row start + node offset) relative to u = 0
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool is_m = pass == 0 ? (m_far == ALL_ROWS) : (m_far != 0u && m_far != ALL_ROWS);
+      const unsigned long long rb = __ballot(is_m);
+      if (!rb) continue;
+      const int nR = __popcll(rb);
+      // member of rank r sends its lane id to lane r; the others all write to lane 63, which no member targets
+      const int src = __builtin_amdgcn_ds_permute((is_m ? __popcll(rb & lt) : 63) << 2, lane);
+      for (int g0 = 0; g0 < nR; g0 += 8) {
+        const int e = g0 + l;
+        const int sl = __builtin_amdgcn_ds_bpermute(e << 2, src);
+        const float qa = pull(sl, f0.x), qc = pull(sl, f0.y), qb1 = pull(sl, f0.z), qb0 = pull(sl, f0.w);
+        float qAy = pull(sl, f1.x), qAy0 = pull(sl, f1.y);
+        const float qub = pull(sl, ub);
+        const float x0 = fmaf(qub, qa, fmaf(off_j, qa, qc));  // x of node j in row 0
+        const float dx = 64.0f * qa;
+        if (pass == 0) {
+          if (e >= nR) { qAy = 0.f; qAy0 = 0.f; }  // empty slot of the last group: numerator 0 on every row
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) {
-            const float x = fmaf(qub + (float)(64 * r), qa, cj);
+            const float x = fmaf((float)r, dx, x0);
+            const float xx = x * x;
+            const float num = fmaf(xx, qAy, qAy0);
+            const float rden = __builtin_amdgcn_rcpf(fmaf(xx + qb1, xx, qb0));
+            nod[r] = fmaf(num, rden, nod[r]);
+          }
+        } else {
+          int mf = __builtin_amdgcn_ds_bpermute(sl << 2, (int)m_far);
+          mf = e < nR ? mf : 0;
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const float x = fmaf((float)r, dx, x0);
             const float xx = x * x;
             float num = fmaf(xx, qAy, qAy0);
             const float rden = __builtin_amdgcn_rcpf(fmaf(xx + qb1, xx, qb0));
             num = __int_as_float(__float_as_int(num) & __builtin_amdgcn_sbfe(mf, r, 1));
             nod[r] = fmaf(num, rden, nod[r]);
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 4 rows in flight: bounds the registers the scheduler takes
           }
         }
       }
@@ -826,40 +533,14 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
     v += __shfl_xor(v, 8);
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if (lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[CHEB_T_N + r * CHEB_N + lane] = v;
-  }
-#pragma unroll
-  for (int i = 0; i < SC_TPL; ++i) {
-    float v = nodT[i];
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    if (SC_TILE_LEVEL && lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[lane + 8 * i] = v;
+    if (lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[r * CHEB_N + lane] = v;
   }
   __syncthreads();
-  const float* nT0 = reinterpret_cast<const float*>(&s_ent[0][0][0]);
-  const float* nT1 = reinterpret_cast<const float*>(&s_ent[1][0][0]);
-  const float* nT2 = reinterpret_cast<const float*>(&s_ent[2][0][0]);
-  const float* nT3 = reinterpret_cast<const float*>(&s_ent[3][0][0]);
-  // stage 1: thread (r, jj) gathers the four waves' row-level sums and carries the tile-level sums to its row node
+  // stage 1: thread (r, jj) adds the four waves' row-level sums in a fixed order
   if (threadIdx.x < ROWS * CHEB_N) {
-    const int o = CHEB_T_N + threadIdx.x;  // = CHEB_T_N + r * CHEB_N + jj
-    float v = (nT0[o] + nT1[o]) + (nT2[o] + nT3[o]);
-    if (SC_TILE_LEVEL) {
-      const float4* __restrict__ m1 = reinterpret_cast<const float4*>(CHEB_T_M1[threadIdx.x]);
-      float f = 0.f;
-#pragma unroll
-      for (int m = 0; m < CHEB_T_N / 4; ++m) {
-        const float4 w = m1[m];
-        const int c = 4 * m;
-        f = fmaf(w.x, (nT0[c] + nT1[c]) + (nT2[c] + nT3[c]), f);
-        f = fmaf(w.y, (nT0[c + 1] + nT1[c + 1]) + (nT2[c + 1] + nT3[c + 1]), f);
-        f = fmaf(w.z, (nT0[c + 2] + nT1[c + 2]) + (nT2[c + 2] + nT3[c + 2]), f);
-        f = fmaf(w.w, (nT0[c + 3] + nT1[c + 3]) + (nT2[c + 3] + nT3[c + 3]), f);
-      }
-      v += f;
-    }
-    s_nodsum[threadIdx.x >> 3][threadIdx.x & 7] = v;
+    const int o = threadIdx.x;  // = r * CHEB_N + jj
+    s_nodsum[o >> 3][o & 7] = (reinterpret_cast<const float*>(&s_ent[0][0][0])[o] + reinterpret_cast<const float*>(&s_ent[1][0][0])[o]) +
+                              (reinterpret_cast<const float*>(&s_ent[2][0][0])[o] + reinterpret_cast<const float*>(&s_ent[3][0][0])[o]);
   }
   __syncthreads();
   // stage 2: row nodes -> grid points, plus the four point-by-point copies; coalesced stores
@@ -916,8 +597,7 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   // RADTXFR_DEBUG_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, to time the kernel at reduced occupancy
   static int lds_pad = -1;
   if (lds_pad < 0) { const char* e = getenv("RADTXFR_DEBUG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
-  if (nodal == 2) hipLaunchKernelGGL(voigt_nodal_v1_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
-  else if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
+  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
   else hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
 #if RTX_SC_STAMP
