@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 // 0.18 ms; evaluating those lines at row level costs less than that) -> this form. Measured slower: the point-by-point
 // members broadcast out of their lanes with v_readlane instead of LDS entries (2.78), two point-by-point rows in flight
 // (2.60), entries drained once per round with the records reloaded on overflow (2.69), tiles of 12 / 16 / 24 rows
-// (2.71 / 2.63 / 2.82).
+// (2.71 / 2.63 / 2.82), LDS float adds without return (ds_add_f32) instead of read / fma / write for the point-by-point
+// rows (10.6 ms: the LDS float atomic is several times slower than the plain pair).
 #ifndef RTX_SC_WAVES
 #define RTX_SC_WAVES 6
 #endif
@@ -385,6 +386,9 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
   for (int r = 0; r < ROWS; ++r) acc[r * 64 + lane] = 0.f;
   const float lanef = (float)lane;
   bool touched = false;
+  long long t_ph[SC_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};  // debug builds (RTX_SC_STAMP): per-phase cycle totals
+  long long t_prev = RTX_SC_STAMP ? (long long)clock64() : 0;
+  const long long t_begin = t_prev;
 
   // node evaluations: lane = (member l of the group, node j)
   const int l = lane >> 3, j = lane & 7;
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
       unsigned m_pp = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.x));
       unsigned m_bd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.y));
       const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(e3.z));
+      STAMP(3);  // entry read
       // far-wing rows, point by point, lanes outside the window masked (interior rows: mask all-true)
       if (RTX_SC_ABLATE & 4) m_pp = 0u;
       while (m_pp) {
@@ -421,6 +426,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
         n0 = (u >= ulo && u < uhi) ? n0 : 0.f;
         p[0] = fmaf(n0, d0, p[0]);
       }
+      STAMP(4);  // point-by-point rows
       if (RTX_SC_ABLATE & 1) m_bd = 0u;
       const bool small_y = q.y < 1.0f;
       while (m_bd) {
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
         band_row<false>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
         p[0] = fmaf(num, rden, p[0]);
       }
+      STAMP(5);  // band rows
     }
     n_ent = 0;
   };
@@ -458,6 +465,8 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
     const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;     // near-zone rows and window edges
     const float ub = (float)(ia - qi0);  // integer-valued
     constexpr unsigned ALL_ROWS = (1u << ROWS) - 1u;
+    if (RTX_SC_STAMP && __ballot(m_pp == 0xffffffffu)) t_ph[7] += 1;  // (forces the masks, i.e. the record loads, before the stamp)
+    STAMP(0);  // record loads + geometry
 
     // ---- point-by-point rows: 64-byte entries, drained by the whole wave ---------------------------------------
     {
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
         eb = __ballot(emit);
       }
     }
+    STAMP(1);  // entry emission
     // ---- row level, 8 member lines per pass; x of node j in row r = x0 + r dx (one FMA per row) ----------------
     // full members first (no masks), then the partial ones
 #pragma unroll
@@ -523,6 +533,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
         }
       }
     }
+    STAMP(2);  // row level
   }
   drain();
 
@@ -535,7 +546,9 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
     v += __shfl_xor(v, 32);
     if (lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[r * CHEB_N + lane] = v;
   }
+  STAMP(2);
   __syncthreads();
+  STAMP(6);  // barrier
   // stage 1: thread (r, jj) adds the four waves' row-level sums in a fixed order
   if (threadIdx.x < ROWS * CHEB_N) {
     const int o = threadIdx.x;  // = r * CHEB_N + jj
@@ -561,6 +574,13 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
         if (a.out32) a.out32[o] = v;
         if (a.out64) a.out64[o] = (double)v * a.inv_scale;
       }
+    }
+  }
+  if (RTX_SC_STAMP) {
+    t_ph[7] = (long long)clock64() - t_begin;  // lifetime (includes the final stages, which have no bucket of their own)
+    if (lane == 0) {
+      unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * SC_NSTAMP;
+      for (int i = 0; i < SC_NSTAMP; ++i) o[i] = (unsigned long long)t_ph[i];
     }
   }
 }
@@ -612,7 +632,7 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
     double h[SC_NSTAMP] = {0};
     for (size_t i = 0; i < n_stamp; ++i) h[i % SC_NSTAMP] += (double)hbuf[i];
     const double w = 4.0 * 8 * a.tiles_per_xcd * n_layers;
-    fprintf(stderr, "[stamp] per wave (s_memtime ticks): load+geom %.0f far %.0f emit %.0f entry %.0f pp %.0f band %.0f barrier %.0f life %.0f\n",
+    fprintf(stderr, "[stamp] per wave (s_memtime ticks): load+geom %.0f emit %.0f rowlevel %.0f entry %.0f pp %.0f band %.0f barrier %.0f life %.0f\n",
             h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
   }
 #endif
