@@ -352,7 +352,10 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 // members broadcast out of their lanes with v_readlane instead of LDS entries (2.78), two point-by-point rows in flight
 // (2.60), entries drained once per round with the records reloaded on overflow (2.69), tiles of 12 / 16 / 24 rows
 // (2.71 / 2.63 / 2.82), LDS float adds without return (ds_add_f32) instead of read / fma / write for the point-by-point
-// rows (10.6 ms: the LDS float atomic is several times slower than the plain pair).
+// rows (10.6 ms: the LDS float atomic is several times slower than the plain pair), row ownership -- each wave owns rows
+// w, w+4, ... with register accumulators, the entries of all four waves shared through LDS behind two barriers per round,
+// no private tile copies (2.68: the point-by-point rows are bound by their own arithmetic, ~41 SIMD cycles per row
+// against a 34-cycle issue cost, not by the LDS round trip, and the shared lists cost more than the copies did).
 #ifndef RTX_SC_WAVES
 #define RTX_SC_WAVES 6
 #endif
