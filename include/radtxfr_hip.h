@@ -160,6 +160,18 @@ int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_layers, con
             int n_angle, int return_od, float* tau, float* Lu, float* Ld, float* Ld_angles,
             int64_t ld_out, void* stream);
 
+/* compute_TUD in ONE call: radiative_transfer.py:274-392 with compute_OD (:395-456, the LBLRTM run) replaced by the
+ * Voigt line-sum -- rtx_line_prep (profile Voigt, scale 1) + rtx_voigt_sum into OD[n_layers][ld_od] + rtx_tud, enqueued
+ * back to back on `stream`. Arguments as for those three entry points; OD is caller-owned (it is also an output: the
+ * reference's returnOD / save options expose it). One FFI crossing per atmosphere instead of three. */
+int rtx_compute_tud(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, int n_layers,
+                    const double* T_h, const double* p_atm_h, const double* qratio_h,
+                    const double* weight_h, const double* mass_h, double dil_air, double dil_self,
+                    double omega_wing, double omega_wing_hw, double intensity_threshold, int n_alt,
+                    const uint8_t* mask_h, int n_mu, const double* mu_h, int n_down, int n_angle,
+                    int return_od, float* OD, int64_t ld_od, float* tau, float* Lu, float* Ld,
+                    int64_t ld_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * At-sensor radiance. Replaces compute_LWIR_apparent_radiance(), radiative_transfer.py:1017-
  * 1069: L = tau*(emis*B(Ts+dT) + (1-emis)*Ld) + La.

@@ -137,10 +137,9 @@ extern "C" int rtx_prep_free(rtx_prep* P) {
   if (P->rec) (void)hipFree(P->rec);
   if (P->rec64) (void)hipFree(P->rec64);
   if (P->ic) (void)hipFree(P->ic);
-  if (P->maxhw) (void)hipFree(P->maxhw);
+  if (P->maxhw) (void)hipFree(P->maxhw);  // smally lives in the same allocation
   if (P->env) (void)hipFree(P->env);
   if (P->ranges) (void)hipFree(P->ranges);
-  if (P->smally) (void)hipFree(P->smally);
   if (P->recsd) (void)hipFree(P->recsd);
   delete P;
   return 0;
@@ -165,9 +164,9 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
   hipError_t e = hipMalloc((void**)&P->rec, nrec * sizeof(LineRec));
   if (e == hipSuccess) e = hipMalloc((void**)&P->rec64, nrec * sizeof(LineRec64));
   if (e == hipSuccess) e = hipMalloc((void**)&P->ic, sizeof(int) * (size_t)(lines->n > 0 ? lines->n : 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&P->maxhw, sizeof(int) * (size_t)max_layers);
+  if (e == hipSuccess) e = hipMalloc((void**)&P->maxhw, 2 * sizeof(int) * (size_t)max_layers);  // [maxhw | smally]: one memset per prologue
+  if (e == hipSuccess) P->smally = P->maxhw + max_layers;
   if (e == hipSuccess) e = hipMalloc((void**)&P->env, sizeof(double) * P->env_cap);
-  if (e == hipSuccess) e = hipMalloc((void**)&P->smally, sizeof(int) * (size_t)max_layers);
   if (e == hipSuccess) e = hipMalloc((void**)&P->ranges, sizeof(int2) * (size_t)P->max_tiles * (size_t)max_layers);
   if (e != hipSuccess) {
     rtx_set_error("rtx_prep_create: %s (%zu records)", hipGetErrorString(e), nrec);
@@ -185,6 +184,7 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
 #define H_CMASSMOL 1.66053873e-27
 #define H_C2 1.4388028496642257
 #define H_TREF 296.0
+#define RTX_ENV_MAX 416  /* doubles of per-layer tables carried in the prologue's kernel arguments (3.3 KB of the 4 KB) */
 
 struct PrepArgs {
   const double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
@@ -193,7 +193,8 @@ struct PrepArgs {
   const int* species;
   long long n_lines;
   int n_layers, n_species;
-  const double *T, *p, *qratio, *weight, *mass;  // device copies of the small per-layer tables
+  const double *T, *p, *qratio, *weight, *mass;  // the small per-layer tables: device copies, or offsets into env[] (ENV_ARGS)
+  double env[RTX_ENV_MAX];                       // T | p | qratio | weight | mass packed, when they fit (no H2D copy at all)
   double dil_air, dil_self, omega_wing, omega_wing_hw, thresh, scale;
   int profile;  // RTX_PROFILE_VOIGT / _LORENTZ / _DOPPLER
   GridDev g;
@@ -204,6 +205,9 @@ struct PrepArgs {
   int* smally;
 };
 
+// The per-layer tables (T, p, qratio, weight, mass: 324 doubles for 4 species x 32 layers) travel in the kernel arguments
+// when they fit: the prologue then needs no host-to-device copy, which was 5 hipMemcpyAsync calls (~10 us of host time
+// each) per atmosphere. Larger sets go through the prep object's device buffer as before.
 // bisect.bisect (= bisect_right) of value v on the FULL grid: number of grid points <= v.
 __device__ long long grid_bisect_right(const GridDev& g, double v) {
   double t = (v - g.xmin) / g.step;
@@ -232,26 +236,33 @@ __device__ __forceinline__ int sat_local(long long v, long long n) {
   return (int)(v < -M ? -M : (v > n + M ? n + M : v));
 }
 
+template <bool ENV_ARGS>
 __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
   const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
   int my_hw = 0;
+  // ENV_ARGS: a.T ... a.mass hold element offsets into a.env (kernel-argument segment), else device pointers
+  const double* eT = ENV_ARGS ? a.env + (size_t)a.T : a.T;
+  const double* ep = ENV_ARGS ? a.env + (size_t)a.p : a.p;
+  const double* eq = ENV_ARGS ? a.env + (size_t)a.qratio : a.qratio;
+  const double* ew = ENV_ARGS ? a.env + (size_t)a.weight : a.weight;
+  const double* em = ENV_ARGS ? a.env + (size_t)a.mass : a.mass;
   if (l < a.n_lines) {
     const GridDev& g = a.g;
-    const double T = a.T[k], p = a.p[k];
+    const double T = eT[k], p = ep[k];
     const double nu = a.nu[l];
     const int sp = a.species[l];
-    const double w = a.weight[(size_t)sp * a.n_layers + k];
+    const double w = ew[(size_t)sp * a.n_layers + k];
     // S(T): EnvironmentDependency_Intensity, misc/hapi.py:10169-10175 (SigmaTref/SigmaT = qratio)
     const double el = a.elower[l];
     const double ch = exp(-H_C2 * el / T) * (1.0 - exp(-H_C2 * nu / T));
     const double zn = exp(-H_C2 * el / H_TREF) * (1.0 - exp(-H_C2 * nu / H_TREF));
-    const double S = a.sw[l] * a.qratio[(size_t)sp * a.n_layers + k] * ch / zn;
+    const double S = a.sw[l] * eq[(size_t)sp * a.n_layers + k] * ch / zn;
     // GammaD, misc/hapi.py:11085-11087
-    const double m = a.mass[sp] * H_CMASSMOL * 1000.0;
+    const double m = em[sp] * H_CMASSMOL * 1000.0;
     double GammaD = sqrt(2.0 * H_CBOLTS * T * log(2.0) / m / (H_CC * H_CC)) * nu;
     if (a.profile == RTX_PROFILE_DOPPLER)  // absorptionCoefficient_Doppler's own SI constants, misc/hapi.py:11534-11538
-      GammaD = (1.1774100225 / 2.99792458e8) * sqrt(1.3806503e-23 / 1.66053873e-27) * sqrt(T) * nu / sqrt(a.mass[sp]);
+      GammaD = (1.1774100225 / 2.99792458e8) * sqrt(1.3806503e-23 / 1.66053873e-27) * sqrt(T) * nu / sqrt(em[sp]);
     // Gamma0 / Shift0 over the diluent mix, misc/hapi.py:11090-11128
     double Gamma0 = 0.0, Shift0 = 0.0;
     const double tr = H_TREF / T;
@@ -380,15 +391,17 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
   const int ns = L->n_species;
   const size_t nT = (size_t)n_layers, nQ = (size_t)ns * n_layers;
   if (2 * nT + 2 * nQ + ns > P->env_cap) RTX_FAIL("environment tables exceed prep capacity");
+  const bool env_args = 2 * nT + 2 * nQ + ns <= RTX_ENV_MAX;
   double* d = P->env;
-  // pageable-source async copies are staged by the runtime before returning: caller may reuse its arrays
-  RTX_HIP(hipMemcpyAsync(d, T_h, nT * sizeof(double), hipMemcpyHostToDevice, st));
-  RTX_HIP(hipMemcpyAsync(d + nT, p_atm_h, nT * sizeof(double), hipMemcpyHostToDevice, st));
-  RTX_HIP(hipMemcpyAsync(d + 2 * nT, qratio_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
-  RTX_HIP(hipMemcpyAsync(d + 2 * nT + nQ, weight_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
-  RTX_HIP(hipMemcpyAsync(d + 2 * nT + 2 * nQ, mass_h, ns * sizeof(double), hipMemcpyHostToDevice, st));
-  RTX_HIP(hipMemsetAsync(P->maxhw, 0, sizeof(int) * (size_t)n_layers, st));
-  RTX_HIP(hipMemsetAsync(P->smally, 0, sizeof(int) * (size_t)n_layers, st));
+  if (!env_args) {
+    // pageable-source async copies are staged by the runtime before returning: caller may reuse its arrays
+    RTX_HIP(hipMemcpyAsync(d, T_h, nT * sizeof(double), hipMemcpyHostToDevice, st));
+    RTX_HIP(hipMemcpyAsync(d + nT, p_atm_h, nT * sizeof(double), hipMemcpyHostToDevice, st));
+    RTX_HIP(hipMemcpyAsync(d + 2 * nT, qratio_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
+    RTX_HIP(hipMemcpyAsync(d + 2 * nT + nQ, weight_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
+    RTX_HIP(hipMemcpyAsync(d + 2 * nT + 2 * nQ, mass_h, ns * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  RTX_HIP(hipMemsetAsync(P->maxhw, 0, 2 * sizeof(int) * (size_t)P->max_layers, st));  // maxhw and smally
   P->n_layers = n_layers;
   P->scale = scale;
   if (L->n == 0) return 0;
@@ -398,13 +411,24 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
   a.delta_self = L->delta_self; a.species = L->species;
   a.sd_air = L->sd_air; a.sd_self = L->sd_self; a.deltap_self = L->deltap_self; a.recsd = P->recsd;
   a.n_lines = L->n; a.n_layers = n_layers; a.n_species = ns;
-  a.T = d; a.p = d + nT; a.qratio = d + 2 * nT; a.weight = d + 2 * nT + nQ; a.mass = d + 2 * nT + 2 * nQ;
+  if (env_args) {  // offsets (in doubles) into a.env, carried in the pointer fields
+    a.T = (const double*)(size_t)0; a.p = (const double*)nT; a.qratio = (const double*)(2 * nT);
+    a.weight = (const double*)(2 * nT + nQ); a.mass = (const double*)(2 * nT + 2 * nQ);
+    memcpy(a.env, T_h, nT * sizeof(double));
+    memcpy(a.env + nT, p_atm_h, nT * sizeof(double));
+    memcpy(a.env + 2 * nT, qratio_h, nQ * sizeof(double));
+    memcpy(a.env + 2 * nT + nQ, weight_h, nQ * sizeof(double));
+    memcpy(a.env + 2 * nT + 2 * nQ, mass_h, ns * sizeof(double));
+  } else {
+    a.T = d; a.p = d + nT; a.qratio = d + 2 * nT; a.weight = d + 2 * nT + nQ; a.mass = d + 2 * nT + 2 * nQ;
+  }
   a.dil_air = dil_air; a.dil_self = dil_self; a.omega_wing = omega_wing; a.omega_wing_hw = omega_wing_hw;
   a.thresh = intensity_threshold; a.scale = scale; a.profile = profile;
   a.g = to_dev(grid);
   a.rec = P->rec; a.rec64 = P->rec64; a.ic = P->ic; a.maxhw = P->maxhw; a.smally = P->smally;
   dim3 grd((unsigned)((L->n + 255) / 256), (unsigned)n_layers);
-  hipLaunchKernelGGL(line_prep_kernel, grd, dim3(256), 0, st, a);
+  if (env_args) hipLaunchKernelGGL(line_prep_kernel<true>, grd, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(line_prep_kernel<false>, grd, dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }

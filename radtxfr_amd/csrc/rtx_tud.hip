@@ -439,3 +439,23 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
   if (na <= 29) return launch_tud<29>(a, na, st);
   return launch_tud<32>(a, na, st);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// compute_TUD in one call (radiative_transfer.py:274-392 with compute_OD := the Voigt line-sum): prologue, line-sum and
+// TUD integration enqueued back to back. Same kernels as the three separate entry points; what it saves is host time per
+// atmosphere (one FFI crossing, no per-call Python marshalling between the stages), which is what limits a wavenumber
+// shard small enough to finish in a few hundred microseconds (8-GPU strong scaling, tools/time_overhead.py).
+extern "C" int rtx_compute_tud(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, int n_layers, const double* T_h,
+                               const double* p_atm_h, const double* qratio_h, const double* weight_h, const double* mass_h,
+                               double dil_air, double dil_self, double omega_wing, double omega_wing_hw,
+                               double intensity_threshold, int n_alt, const uint8_t* mask_h, int n_mu, const double* mu_h,
+                               int n_down, int n_angle, int return_od, float* OD, int64_t ld_od, float* tau, float* Lu,
+                               float* Ld, int64_t ld_out, void* stream) {
+  if (!OD) RTX_FAIL("OD workspace is NULL");
+  if (rtx_line_prep_profile(prep, lines, grid, n_layers, T_h, p_atm_h, qratio_h, weight_h, mass_h, dil_air, dil_self, omega_wing,
+                            omega_wing_hw, intensity_threshold, 1.0, RTX_PROFILE_VOIGT, stream))
+    return 1;
+  if (rtx_voigt_sum(prep, grid, n_layers, OD, nullptr, ld_od, stream)) return 1;
+  return rtx_tud(OD, ld_od, grid, n_layers, T_h, n_alt, mask_h, n_mu, mu_h, n_down, n_angle, return_od, tau, Lu, Ld, nullptr,
+                 ld_out, stream);
+}

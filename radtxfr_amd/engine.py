@@ -329,6 +329,76 @@ def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=Fals
     return tau, Lu, Ld, (Z_s.size, mu_s.size)
 
 
+class TudRunner:
+    """compute_TUD for a stream of atmospheres on one spectral grid / line table / altitude grid (the reference's outer
+    loop, Generate_LWIR_TUD.py:117-150): everything that does not depend on the atmosphere -- grid, prep object, sensor
+    altitude masks, slant factors, device buffers, the ctypes argument objects -- is set up once; run() does the
+    per-atmosphere host factors (TIPS ratios, column weights) and ONE call into the library (rtx_compute_tud: prologue +
+    line-sum + TUD enqueued back to back). Outputs are float32 device tensors owned by the runner (or `out`), overwritten
+    by the next run(): tau, Lu [nAlt*nMu][n], Ld [n], OD [nL][n]."""
+
+    def __init__(self, lines, grid, Z, n_layers=None, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=False, out=None,
+                 OD=None):
+        self.lib = _lib.load()
+        self.lines, self.grid = lines, grid
+        Z = np.atleast_1d(np.asarray(Z, dtype=np.float64))
+        self.nL = int(Z.size if n_layers is None else n_layers)
+        Z_s = np.array([Altitudes], dtype=np.float64).ravel()
+        self.mu = np.ascontiguousarray(np.array([1.0 / np.cos(np.asarray(theta_r, dtype=np.float64))], dtype=np.float64).ravel())
+        if self.mu.size > TUD_MAX_MU:
+            raise ValueError("TudRunner takes at most %d slant paths" % TUD_MAX_MU)
+        self.mask = np.ascontiguousarray(np.stack([(Z <= zs) for zs in Z_s]).astype(np.uint8))
+        self.n_down = int(self.mask[-1].sum())  # quirk 3: the LAST altitude's layer count (:353, :370)
+        self.shape = (Z_s.size, self.mu.size)
+        self.N_angle, self.returnOD = int(N_angle), int(bool(returnOD))
+        dev = device()
+        nrow = Z_s.size * self.mu.size
+        self.OD = OD if OD is not None else torch.empty((self.nL, grid.n), dtype=torch.float32, device=dev)
+        if out is None:
+            self.tau = torch.empty((nrow, grid.n), dtype=torch.float32, device=dev)
+            self.Lu = torch.empty_like(self.tau)
+            self.Ld = torch.empty((grid.n,), dtype=torch.float32, device=dev)
+        else:
+            self.tau, self.Lu, self.Ld = out
+        self.set_outputs(self.tau, self.Lu, self.Ld)
+        self.plan = lines.plan(self.nL, grid.n)
+        self._env = np.empty(2 * self.nL + 2 * len(lines.species) * self.nL + len(lines.species), dtype=np.float64)
+
+    def set_outputs(self, tau, Lu, Ld):
+        """Point the next run() at other output tensors (e.g. the other half of a double-buffered packed block)."""
+        nrow = self.shape[0] * self.shape[1]
+        for t in (tau, Lu):
+            assert t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and t.shape[0] == nrow
+            assert t.shape[1] >= self.grid.n and t.stride(1) == 1 and t.stride(0) == tau.stride(0)
+        assert Ld.dtype == torch.float32 and Ld.is_cuda and Ld.numel() >= self.grid.n and Ld.stride(0) == 1
+        self.tau, self.Lu, self.Ld = tau, Lu, Ld
+        self._ld_out = tau.stride(0) if tau.shape[0] > 1 else max(tau.shape[1], self.grid.n)
+        self._ptrs = (C.c_void_p(tau.data_ptr()), C.c_void_p(Lu.data_ptr()), C.c_void_p(Ld.data_ptr()))
+
+    def run(self, T, P_pa, PL_km, MF_VAL, MF_ID, partitionFunction=None):
+        nL, lines = self.nL, self.lines
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        assert T.size == nL
+        w, p_atm = layer_weights_od(lines.species, T, P_pa, PL_km, MF_VAL, MF_ID)
+        qratio, mass = species_factors(lines.species, T, partitionFunction, weight=w)
+        nS = len(lines.species)
+        env = self._env  # T | p | qratio | weight | mass, one contiguous host block
+        env[0:nL] = T
+        env[nL:2 * nL] = p_atm
+        env[2 * nL:2 * nL + nS * nL] = qratio.ravel()
+        env[2 * nL + nS * nL:2 * nL + 2 * nS * nL] = w.ravel()
+        env[2 * nL + 2 * nS * nL:] = mass
+        base = env.ctypes.data
+        vp = C.c_void_p
+        _lib.check(self.lib.rtx_compute_tud(
+            self.plan._h, lines._h, self.grid.byref(), nL, vp(base), vp(base + 8 * nL), vp(base + 16 * nL),
+            vp(base + 8 * (2 * nL + nS * nL)), vp(base + 8 * (2 * nL + 2 * nS * nL)), 1.0, 0.0, 0.0, 50.0, 0.0,
+            self.shape[0], self.mask.ctypes.data_as(vp), self.shape[1], self.mu.ctypes.data_as(vp), self.n_down, self.N_angle,
+            self.returnOD, vp(self.OD.data_ptr()), self.OD.stride(0), self._ptrs[0], self._ptrs[1], self._ptrs[2], self._ld_out,
+            _stream_ptr()))
+        return self.tau, self.Lu, self.Ld
+
+
 def planck(X, T, wavelength=False, grid=None):
     """out[nx][nT] float64 device tensor (rtx_planck). X: device fp64 tensor, or None with a Grid."""
     lib = _lib.load()

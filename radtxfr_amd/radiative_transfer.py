@@ -174,6 +174,66 @@ def compute_OD(Xmin_in, Xmax_in, opts=options, **kwargs):
     return X, OD[0].double().cpu().numpy()
 
 
+_AXIS_CACHE = {}
+
+
+def _cached_axis(Xmin, Xmax, DVOUT):
+    """make_spectral_axis with a two-entry cache: np.linspace of the 5.5 M-point C3 axis costs ~12 ms of host time per call,
+    more than the whole device computation. The cached array is returned READ-ONLY (every call on the same grid hands out the
+    same object); callers that want to modify it copy it."""
+    key = (float(Xmin), float(Xmax), float(DVOUT))
+    X = _AXIS_CACHE.get(key)
+    if X is None:
+        X = make_spectral_axis(Xmin, Xmax, DVOUT)
+        X.setflags(write=False)
+        if len(_AXIS_CACHE) >= 2:
+            _AXIS_CACHE.pop(next(iter(_AXIS_CACHE)))
+        _AXIS_CACHE[key] = X
+    return X
+
+
+def _rows_to_host_f64(rows, stream=None):
+    """float32 device rows [(k_i, n)] -> float64 NumPy arrays: widened on the DEVICE into one block, one asynchronous copy
+    into pinned host memory (PyTorch's caching pinned allocator: no allocation after the first call of a size), views handed
+    out. Returns (arrays, event): the arrays are valid once `event` has completed (event.synchronize())."""
+    n = rows[0].shape[-1]
+    ks = [int(np.prod(r.shape[:-1])) if r.dim() > 1 else 1 for r in rows]
+    dev_block = torch.empty((sum(ks), n), dtype=torch.float64, device=rows[0].device)
+    o = 0
+    for r, k in zip(rows, ks):
+        dev_block[o:o + k].copy_(r.reshape(k, n))
+        o += k
+    host = torch.empty((sum(ks), n), dtype=torch.float64, pin_memory=True)
+    side = stream if stream is not None else torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record()  # the widening runs on the current (compute) stream
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        host.copy_(dev_block, non_blocking=True)
+        dev_block.record_stream(side)
+        done = torch.cuda.Event()
+        done.record(side)
+    arr = host.numpy()
+    out, o = [], 0
+    for k in ks:
+        out.append(arr[o:o + k])
+        o += k
+    return out, done
+
+
+def _tud_shapes(tau2, Lu2, nZ, nMu):
+    """The reference's squeeze rules (:357-365) on [nZ*nMu][nX] host rows."""
+    tau_ = tau2.reshape(nZ, nMu, -1).transpose(2, 0, 1)
+    Lu_ = Lu2.reshape(nZ, nMu, -1).transpose(2, 0, 1)
+    if nZ == 1 and nMu == 1:
+        return tau_[:, 0, 0], Lu_[:, 0, 0]
+    if nZ == 1:
+        return np.ascontiguousarray(tau_[:, 0, :]), np.ascontiguousarray(Lu_[:, 0, :])
+    if nMu == 1:
+        return np.ascontiguousarray(tau_[:, :, 0]), np.ascontiguousarray(Lu_[:, :, 0])
+    return np.ascontiguousarray(tau_), np.ascontiguousarray(Lu_)
+
+
 def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     """Monochromatic transmittance, upwelling and downwelling radiance, signature of :274-392.
 
@@ -182,6 +242,7 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     (nX,nZ,nMu) by the reference's squeeze rules (:357-365); Ld is (nX,).
     Quirks 3-6 of SURVEY.md section 9 are reproduced (downwelling uses the layer count of the last
     sensor altitude; tau uses the Z<=zs mask, L-up the first count layers; returnOD; theta=0 weight 0).
+    X is a cached read-only array (see _cached_axis); the spectra are fresh float64 arrays in pinned host memory.
     """
     o = dict(opts)
     o.update(kwargs)
@@ -195,27 +256,102 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     f = lambda x: np.array([x]).ravel()
     Z_s = f(o["Altitudes"])
     mu_s = f(1.0 / np.cos(o["theta_r"]))
-    X_ = make_spectral_axis(Xmin, Xmax, o["DVOUT"])
+    X_ = _cached_axis(Xmin, Xmax, o["DVOUT"])
     grid = engine.Grid(Xmin, Xmax, X_.size)
     tbl = _resolve_table(o.get("line_table"))
-    OD = engine.optical_depths(tbl, grid, T, P, PL, MF, ID)  # [nL][nX] float32 on the device
-    res = engine.tud(OD, grid, T, Z, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64), N_angle=nA,
-                     returnOD=bool(o["returnOD"]), per_angle=bool(o["save"]))
-    tau, Lu, Ld, (nZ, nMu) = res[:4]
-    tau_ = tau.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1)
-    Lu_ = Lu.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1)
-    Ld_ = Ld.double().cpu().numpy()
+    if mu_s.size <= engine.TUD_MAX_MU and not o["save"]:
+        # the common case: one call into the library (rtx_compute_tud)
+        run = engine.TudRunner(tbl, grid, Z, n_layers=T.size, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64),
+                               N_angle=nA, returnOD=bool(o["returnOD"]))
+        tau, Lu, Ld = run.run(T, P, PL, MF, ID)
+        nZ, nMu = run.shape
+        OD = run.OD
+    else:
+        OD = engine.optical_depths(tbl, grid, T, P, PL, MF, ID)  # [nL][nX] float32 on the device
+        res = engine.tud(OD, grid, T, Z, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64), N_angle=nA,
+                         returnOD=bool(o["returnOD"]), per_angle=bool(o["save"]))
+        tau, Lu, Ld, (nZ, nMu) = res[:4]
+    (tau_h, Lu_h, Ld_h), done = _rows_to_host_f64([tau, Lu, Ld[None, :]])
+    done.synchronize()
+    tau_, Lu_ = _tud_shapes(tau_h, Lu_h, nZ, nMu)
+    Ld_ = Ld_h[0]
     if o["save"]:
         angles = np.linspace(0, np.pi / 2.0, nA, endpoint=False)
-        np.savez("ComputeTUD.npz", OD=OD.double().cpu().numpy().T, B=planckian(X_, T), tau=tau_, Ld=res[4].double().cpu().numpy().T,
-                 Lu=Lu_, X=X_, angles=angles, Z_s=Z_s, mu_s=mu_s)
-    if (len(Z_s) == 1) and (len(mu_s) == 1):
-        tau_, Lu_ = tau_[:, 0, 0], Lu_[:, 0, 0]
-    elif len(Z_s) == 1:
-        tau_, Lu_ = tau_[:, 0, :], Lu_[:, 0, :]
-    elif len(mu_s) == 1:
-        tau_, Lu_ = tau_[:, :, 0], Lu_[:, :, 0]
-    return X_, np.ascontiguousarray(tau_), np.ascontiguousarray(Lu_), Ld_
+        t3 = tau_h.reshape(nZ, nMu, -1).transpose(2, 0, 1)
+        u3 = Lu_h.reshape(nZ, nMu, -1).transpose(2, 0, 1)
+        np.savez("ComputeTUD.npz", OD=OD.double().cpu().numpy().T, B=planckian(X_, T), tau=t3, Ld=res[4].double().cpu().numpy().T,
+                 Lu=u3, X=X_, angles=angles, Z_s=Z_s, mu_s=mu_s)
+    return X_, tau_, Lu_, Ld_
+
+
+def compute_TUD_batch(Xmin, Xmax, atmospheres, opts=options, reduce=None, **kwargs):
+    """compute_TUD for MANY atmospheres on one spectral grid -- the reference's outer loop
+    (Generate_LWIR_TUD.py:117-150: 199 atmospheres x `rt.compute_TUD(..., MFs_VAL=, Ts=, ...)`, fanned out over a
+    multiprocessing.Pool there) as a device pipeline: atmosphere k's widening and device-to-host copy run on a side stream
+    while atmosphere k+1's kernels run on the compute stream.
+
+    atmospheres: sequence of dicts with any of Ts, Ps, PLs, MFs_VAL (the per-atmosphere kwargs of the reference's caller);
+    everything else (Zs, MFs_ID, DVOUT, Altitudes, theta_r, N_angle, returnOD, line_table) comes from opts / kwargs and is
+    common to the batch. reduce = dict(dX=..., N=4, window="hanning") applies reduceResolution (:1327-1350) to tau, Lu and
+    Ld on the device, as the reference's caller does right after each compute_TUD (Generate_LWIR_TUD.py:124-126): only the
+    reduced spectra cross PCIe then.
+    Returns a list of (X, tau, Lu, Ld) with the shapes compute_TUD gives (X_out instead of X when reduce is set)."""
+    o = dict(opts)
+    o.update(kwargs)
+    if o["save"]:
+        raise ValueError("compute_TUD_batch: save is a single-call option")
+    Z = np.asarray(o["Zs"], dtype=np.float64)
+    ID = np.asarray(o["MFs_ID"])
+    f = lambda x: np.array([x]).ravel()
+    Z_s = f(o["Altitudes"])
+    mu_s = f(1.0 / np.cos(o["theta_r"]))
+    if mu_s.size > engine.TUD_MAX_MU:
+        raise ValueError("compute_TUD_batch takes at most %d slant paths" % engine.TUD_MAX_MU)
+    X_ = _cached_axis(Xmin, Xmax, o["DVOUT"])
+    grid = engine.Grid(Xmin, Xmax, X_.size)
+    tbl = _resolve_table(o.get("line_table"))
+    nL = np.asarray(o["Ts"]).size
+    # two runners = two sets of device outputs: the copy of one is in flight while the other is being computed
+    mk = lambda OD: engine.TudRunner(tbl, grid, Z, n_layers=nL, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64),
+                                     N_angle=int(o["N_angle"]), returnOD=bool(o["returnOD"]), OD=OD)
+    runs = [mk(None)]
+    runs.append(mk(runs[0].OD))  # the layer optical depths are consumed on the compute stream: one buffer is enough
+    nZ, nMu = runs[0].shape
+    side = torch.cuda.Stream()
+    busy = [None, None]     # copy-done event of the runner's outputs
+    pending = []            # (host rows, done event, X of the result)
+    results = []
+
+    def finish(item):
+        (tau_h, Lu_h, Ld_h), done, Xr = item
+        done.synchronize()
+        tau_, Lu_ = _tud_shapes(tau_h, Lu_h, nZ, nMu)
+        results.append((Xr, tau_, Lu_, Ld_h[0]))
+
+    for k, atm in enumerate(atmospheres):
+        a = dict(o)
+        a.update(atm)
+        run = runs[k & 1]
+        if busy[k & 1] is not None:
+            torch.cuda.current_stream().wait_event(busy[k & 1])  # its previous outputs have left the device
+        tau, Lu, Ld = run.run(np.asarray(a["Ts"], dtype=np.float64), np.asarray(a["Ps"], dtype=np.float64),
+                              np.asarray(a["PLs"], dtype=np.float64), np.asarray(a["MFs_VAL"], dtype=np.float64), ID)
+        Xr = X_
+        if reduce is not None:
+            rows = torch.cat([tau, Lu, Ld[None, :]])
+            Xr, red = engine.reduce_resolution(rows, float(X_[0]), grid.step, grid.n, float(reduce["dX"]), N=reduce.get("N", 4),
+                                               window=reduce.get("window", "hanning"))
+            nr = tau.shape[0]
+            host_rows, done = _rows_to_host_f64([red[:nr], red[nr:2 * nr], red[2 * nr:]], stream=side)
+        else:
+            host_rows, done = _rows_to_host_f64([tau, Lu, Ld[None, :]], stream=side)
+        busy[k & 1] = done
+        pending.append((host_rows, done, Xr))
+        if len(pending) > 1:
+            finish(pending.pop(0))
+    while pending:
+        finish(pending.pop(0))
+    return results
 
 
 def compute_LWIR_apparent_radiance(X, emis, Ts, tau, La, Ld, dT=None, return_Ls=False):

@@ -1063,3 +1063,62 @@ def test_g13_compute_tud_vector_theta_golden(rt, golden):
                                             Altitudes=[3.0, 9.0], theta_r=th9)
     assert tau.shape == tau_r.shape == (X.size, 2, 9)
     assert np.max(np.abs(tau - tau_r)) <= TOL_TAU and rel_err(Lu, Lu_r) <= TOL_L and rel_err(Ld, Ld_r) <= TOL_L
+
+
+def test_compute_tud_batch_equals_per_call_results(rt):
+    """compute_TUD_batch (the reference's loop over atmospheres, Generate_LWIR_TUD.py:117-150, as a device pipeline: the
+    copy of atmosphere k overlaps the kernels of k+1, double-buffered outputs) returns exactly what one compute_TUD call
+    per atmosphere returns; with reduce= it returns what reduceResolution makes of those (Generate_LWIR_TUD.py:124-126)."""
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    lo, hi = 1000.0, 1004.0
+    sub = synthetic.subset_table(full, lo - 12.0, hi + 12.0)
+    a = synthetic.c3_atmosphere(32)
+    a["MFs_VAL"] = a["MFs_VAL"] * 1e-3
+    rng = np.random.default_rng(3)
+    atms = [dict(Ts=a["Ts"] + rng.normal(0, 2.0, 32), MFs_VAL=a["MFs_VAL"] * rng.uniform(0.5, 1.5, (32, 1)), Ps=a["Ps"] * s_)
+            for s_ in (1.0, 0.98, 1.01, 1.0, 0.95)]
+    common = dict(DVOUT=0.001, line_table=sub, Zs=a["Zs"], PLs=a["PLs"], MFs_ID=a["MFs_ID"], Ts=a["Ts"], Ps=a["Ps"],
+                  MFs_VAL=a["MFs_VAL"], Altitudes=np.asarray([2.0, 500.0]), theta_r=0.3)
+    got = rt.compute_TUD_batch(lo, hi, atms, **common)
+    assert len(got) == len(atms)
+    for g, atm in zip(got, atms):
+        X, tau, Lu, Ld = rt.compute_TUD(lo, hi, **dict(common, **atm))
+        assert np.array_equal(g[0], X) and g[1].shape == tau.shape == (X.size, 2)
+        assert np.array_equal(g[1], tau) and np.array_equal(g[2], Lu) and np.array_equal(g[3], Ld)
+    assert not np.array_equal(got[0][1], got[1][1])
+    # oracle on one of them
+    k = 2
+    at = dict(common, **atms[k])
+    Xr, tau_r, Lu_r, Ld_r = ref.compute_TUD(sub, lo, hi, 0.001, at["Zs"], at["Ts"], at["Ps"], at["PLs"], at["MFs_VAL"], at["MFs_ID"],
+                                            Altitudes=[2.0, 500.0], theta_r=0.3)
+    assert np.max(np.abs(got[k][1] - tau_r)) <= TOL_TAU and rel_err(got[k][2], Lu_r) <= TOL_L and rel_err(got[k][3], Ld_r) <= TOL_L
+    # reduced on the device
+    red = rt.compute_TUD_batch(lo, hi, atms[:3], reduce=dict(dX=0.25), **common)
+    for g, full_res in zip(red, got):
+        Xo, t_r = rt.reduceResolution(full_res[0], full_res[1], 0.25)
+        assert np.array_equal(g[0], Xo) and g[1].shape == t_r.shape
+        assert rel_err(g[1], t_r) <= 1e-12 and rel_err(g[2], rt.reduceResolution(full_res[0], full_res[2], 0.25, X_out=Xo)) <= 1e-12
+        assert rel_err(g[3], rt.reduceResolution(full_res[0], full_res[3], 0.25, X_out=Xo)) <= 1e-12
+
+
+def test_fused_entry_equals_three_calls():
+    """rtx_compute_tud (engine.TudRunner: one library call per atmosphere, per-layer tables in the prologue's kernel
+    arguments) gives bit-identical tau / L-up / L-down / OD to rtx_line_prep + rtx_voigt_sum + rtx_tud; also with more
+    species x layers than the kernel-argument block holds (the device-buffer path)."""
+    import torch
+    from radtxfr_amd import engine
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    sub = synthetic.subset_table(full, 2340.0, 2362.0)
+    grid = engine.Grid(2350.0, 2352.0, 2000)
+    for nlay in (32, 66):
+        A = synthetic.load_standard_atmosphere()[:nlay]
+        a = dict(Zs=A[:, 1], Ts=A[:, 5], Ps=A[:, 4], PLs=A[:, 3], MFs_VAL=A[:, 6:8] * 1e6 * 1e-2, MFs_ID=np.array([1, 2]))
+        lines = engine.LineTable(sub)
+        assert (2 + 2 * len(lines.species)) * nlay + len(lines.species) > 416 or nlay == 32
+        OD = engine.optical_depths(lines, grid, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+        tau, Lu, Ld, _ = engine.tud(OD, grid, a["Ts"], a["Zs"], Altitudes=[3.0, 500.0], theta_r=0.4)
+        run = engine.TudRunner(lines, grid, a["Zs"], n_layers=nlay, Altitudes=[3.0, 500.0], theta_r=0.4)
+        t2, u2, d2 = run.run(a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+        torch.cuda.synchronize()
+        assert torch.equal(run.OD, OD) and torch.equal(t2, tau) and torch.equal(u2, Lu) and torch.equal(d2, Ld)
+        lines.close()

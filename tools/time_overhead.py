@@ -26,9 +26,28 @@ qratio, mass = engine.species_factors(lines.species, T)
 OD = torch.empty((32, args.n), dtype=torch.float32, device="cuda")
 pk = torch.zeros((3, args.n), dtype=torch.float32, device="cuda")
 
-def step():
+runner = engine.TudRunner(lines, grid, Z, n_layers=32, OD=OD, out=(pk[0:1], pk[1:2], pk[2]))
+
+
+def step_separate():  # round-1 form: three entry points, factors precomputed outside
     engine.voigt_sum(lines, grid, T, p_atm, w, out_f32=OD, qratio=qratio, mass=mass)
     engine.tud(OD, grid, T, Z, out=(pk[0:1], pk[1:2], pk[2]))
+
+
+def step():  # what bench.py runs per step: per-atmosphere host factors + ONE library call (rtx_compute_tud)
+    runner.run(T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
+
+
+for fn, name in ((step_separate, "three calls, factors precomputed"),):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fn()
+    t_h = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    print(f"{name}: host-side {t_h / args.steps * 1e6:.0f} us per step")
 
 for _ in range(20):
     step()
