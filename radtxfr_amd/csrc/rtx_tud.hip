@@ -167,6 +167,8 @@ struct TudArgs {
   float ang_c[TUD_MAX_ANGLES];         // -log2(e)/cos(theta)
   float ang_w[TUD_MAX_ANGLES];         // cos(theta)*sin(theta)
   float ang_cmin, ang_cmax;            // min / max of |ang_c| over the evaluated streams
+  float blk_cmin[TUD_MAX_ANGLES / 4];  // the same per block of 4 consecutive streams (mixed layers pick a form per block)
+  float blk_cmax[TUD_MAX_ANGLES / 4];
   float mu_c[TUD_MAX_MU];              // -log2(e)*mu
   float mu[TUD_MAX_MU];
   unsigned int mask[TUD_MAX_ALT][TUD_MAX_LAYERS / 32];
@@ -343,11 +345,40 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
           L[q] = fmaf(e, B - L[q], L[q]);
         }
       } else {
+        // Mixed layer: neither form holds for every lane AND every stream. The slant factors span 1 .. 19, so a layer
+        // with OD between 0.005 and 0.09 lands here even when all 64 lanes agree; only where the lanes themselves
+        // straddle the switch does a lane need both forms. So the form is chosen per block of 4 consecutive streams
+        // (|c| ascends with the stream index): all lanes thick for the block's most transparent stream -> transmittance
+        // form; all lanes thin for its most oblique one -> emissivity polynomial; else both forms and a per-lane select.
+        const float o2 = od * od;
+        const float A1 = -6.9314718056e-1f * od, A2 = -2.4022650696e-1f * o2, A3 = -5.5504108665e-2f * (o2 * od);
+        const float A4 = -9.6181291076e-3f * (o2 * o2), A5 = -1.3333558146e-3f * (o2 * o2 * od);
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-          const float y = od * cth[q];
-          // per lane: thin through the emissivity, thick through the transmittance (each form cancels in the other regime)
-          L[q] = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - L[q], L[q]) : fmaf(__builtin_amdgcn_exp2f(y), L[q] - B, B);
+        for (int q0 = 0; q0 < NA; q0 += 4) {
+          const int bi = (a0 + q0) >> 2;
+          const bool blk_thick = __ballot(od * a.blk_cmin[bi] >= TUD_THIN_Y) == ~0ull;
+          const bool blk_thin = __ballot(od * a.blk_cmax[bi] < TUD_THIN_Y) == ~0ull;
+          if (blk_thick) {
+#pragma unroll
+            for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
+              const float t = __builtin_amdgcn_exp2f(od * cth[q]);
+              L[q] = fmaf(t, L[q] - B, B);
+            }
+          } else if (blk_thin) {
+#pragma unroll
+            for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
+              const float c = cth[q];
+              const float e = c * fmaf(c, fmaf(c, fmaf(c, fmaf(c, A5, A4), A3), A2), A1);
+              L[q] = fmaf(e, B - L[q], L[q]);
+            }
+          } else {
+#pragma unroll
+            for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
+              const float y = od * cth[q];
+              // per lane: thin through the emissivity, thick through the transmittance (each form cancels in the other regime)
+              L[q] = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - L[q], L[q]) : fmaf(__builtin_amdgcn_exp2f(y), L[q] - B, B);
+            }
+          }
         }
       }
     }
@@ -373,6 +404,12 @@ static int launch_tud(TudArgs& a, int na, hipStream_t st) {
   for (int q = na; q < na_pad; ++q) { a.ang_c[q] = (float)(-LOG2E); a.ang_w[q] = 0.f; }
   a.ang_cmin = cmin; a.ang_cmax = cmax;
   a.n_ang = na_pad;
+  static_assert(NA % 4 == 0 || NA == 29, "stream blocks of 4 start at multiples of NA");
+  for (int q0 = 0; q0 < na_pad; q0 += 4) {  // per block of 4 streams (block index (a0 + q0) / 4 in the kernel: a0 is a multiple of NA)
+    float lo = 3.0e38f, hi = 0.f;
+    for (int q = q0; q < q0 + 4 && q < na_pad; ++q) { lo = fminf(lo, -a.ang_c[q]); hi = fmaxf(hi, -a.ang_c[q]); }
+    a.blk_cmin[q0 >> 2] = lo; a.blk_cmax[q0 >> 2] = hi;
+  }
   const long long blocks = (a.g.n + 255) / 256;
   hipLaunchKernelGGL(tud_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();

@@ -21,4 +21,7 @@ cd "$ROOT"
 # thin-column TUD timing (tools/time_c3.py --mf-scale 1e-3) and the per-step host overhead
 timeout -k 10 200 python3 tools/time_c3.py --reps 5 --mf-scale 1e-3 > "$OUT/time_c3_thin.txt" 2>&1 || exit 4
 timeout -k 10 200 python3 tools/time_overhead.py > "$OUT/time_overhead.txt" 2>&1 || exit 5
+timeout -k 10 300 python3 tools/time_fused_bound.py > "$OUT/time_fused_bound.txt" 2>&1 || exit 6
+# rehearsal of the N = 2 path (two ranks sharing this one GPU over gloo): a record that the code path runs, never a measurement
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --no-cpu-baseline > "$OUT/rehearsal_gloo2.json" 2> "$OUT/rehearsal_gloo2.err" || exit 7
 echo done

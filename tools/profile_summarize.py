@@ -74,7 +74,7 @@ if hit and "SQ_INSTS_VALU" in per[hit[0]]:
     with open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
-for extra in ("rehearsal_gloo2.json", "time_c3_thin.txt", "time_overhead.txt"):
+for extra in ("rehearsal_gloo2.json", "time_c3_thin.txt", "time_overhead.txt", "time_fused_bound.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read()[:1500])
