@@ -167,8 +167,6 @@ struct TudArgs {
   float ang_c[TUD_MAX_ANGLES];         // -log2(e)/cos(theta)
   float ang_w[TUD_MAX_ANGLES];         // cos(theta)*sin(theta)
   float ang_cmin, ang_cmax;            // min / max of |ang_c| over the evaluated streams
-  float blk_cmin[TUD_MAX_ANGLES / 4];  // the same per block of 4 consecutive streams (mixed layers pick a form per block)
-  float blk_cmax[TUD_MAX_ANGLES / 4];
   float mu_c[TUD_MAX_MU];              // -log2(e)*mu
   float mu[TUD_MAX_MU];
   unsigned int mask[TUD_MAX_ALT][TUD_MAX_LAYERS / 32];
@@ -355,9 +353,12 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
         const float A4 = -9.6181291076e-3f * (o2 * o2), A5 = -1.3333558146e-3f * (o2 * o2 * od);
 #pragma unroll
         for (int q0 = 0; q0 < NA; q0 += 4) {
-          const int bi = (a0 + q0) >> 2;
-          const bool blk_thick = __ballot(od * a.blk_cmin[bi] >= TUD_THIN_Y) == ~0ull;
-          const bool blk_thin = __ballot(od * a.blk_cmax[bi] < TUD_THIN_Y) == ~0ull;
+          // |c| ascends with the stream index (pads repeat the last stream): the block's extremes are its end streams,
+          // already in scalar registers -- fetching per-block bounds from the kernel arguments here put a scalar load
+          // and its wait in front of every block
+          const int q1 = q0 + 3 < NA ? q0 + 3 : NA - 1;
+          const bool blk_thick = __ballot(od * -cth[q0] >= TUD_THIN_Y) == ~0ull;
+          const bool blk_thin = __ballot(od * -cth[q1] < TUD_THIN_Y) == ~0ull;
           if (blk_thick) {
 #pragma unroll
             for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
@@ -399,17 +400,13 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
 template <int NA>
 static int launch_tud(TudArgs& a, int na, hipStream_t st) {
   const int na_pad = na == 0 ? NA : ((na + NA - 1) / NA) * NA;  // at least one block: it carries tau and L-up
-  float cmin = (float)LOG2E, cmax = (float)LOG2E;  // the pads are nadir streams and count for the thick/thin test
-  for (int q = 0; q < na; ++q) { cmin = fminf(cmin, -a.ang_c[q]); cmax = fmaxf(cmax, -a.ang_c[q]); }
-  for (int q = na; q < na_pad; ++q) { a.ang_c[q] = (float)(-LOG2E); a.ang_w[q] = 0.f; }
+  float cmin = (float)LOG2E, cmax = (float)LOG2E;
+  for (int q = 0; q < na; ++q) { cmin = q == 0 ? -a.ang_c[q] : fminf(cmin, -a.ang_c[q]); cmax = q == 0 ? -a.ang_c[q] : fmaxf(cmax, -a.ang_c[q]); }
+  // pads: weight-0 copies of the last stream (keeps |c| ascending with the stream index, which the per-block form
+  // selection of mixed layers relies on); with no stream at all, nadir
+  for (int q = na; q < na_pad; ++q) { a.ang_c[q] = na > 0 ? a.ang_c[na - 1] : (float)(-LOG2E); a.ang_w[q] = 0.f; }
   a.ang_cmin = cmin; a.ang_cmax = cmax;
   a.n_ang = na_pad;
-  static_assert(NA % 4 == 0 || NA == 29, "stream blocks of 4 start at multiples of NA");
-  for (int q0 = 0; q0 < na_pad; q0 += 4) {  // per block of 4 streams (block index (a0 + q0) / 4 in the kernel: a0 is a multiple of NA)
-    float lo = 3.0e38f, hi = 0.f;
-    for (int q = q0; q < q0 + 4 && q < na_pad; ++q) { lo = fminf(lo, -a.ang_c[q]); hi = fmaxf(hi, -a.ang_c[q]); }
-    a.blk_cmin[q0 >> 2] = lo; a.blk_cmax[q0 >> 2] = hi;
-  }
   const long long blocks = (a.g.n + 255) / 256;
   hipLaunchKernelGGL(tud_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
