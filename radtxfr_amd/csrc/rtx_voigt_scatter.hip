@@ -45,7 +45,7 @@
 #define RTX_SC_ROWS 20  // rows of 64 points per tile: 1280 points, 5 KiB of LDS per wave copy (measured: 16 -> 5.63 ms, 20 -> 5.35, 24 -> 5.42, 32 -> 6.1)
 #endif
 #ifndef RTX_SC_NEAR
-#define RTX_SC_NEAR 3  // rows either side of the centre row that stay point-by-point in the nodal kernel
+#define RTX_SC_NEAR 2  // rows either side of the centre row that stay point-by-point in the nodal kernel (3: 2.48 ms, interpolation error <= 1.4e-8 of a line's own contribution; 2: 2.34 ms, <= 2.3e-7)
 #endif
 static_assert(RTX_SC_ROWS <= 31, "row masks are 32-bit");
 
@@ -414,14 +414,24 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
       q.Ay = e1.x; q.Ay0 = e1.y; q.y = e1.z; q.A = e1.w;
       const float u0 = e2.x + lanef, ulo = e2.y, uhi = e2.z, zw_f = e2.w;
       unsigned m_pp = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.x));
+      unsigned m_ed = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.w));
       unsigned m_bd = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(e3.y));
       const int slot = __builtin_amdgcn_readfirstlane(__float_as_int(e3.z));
       STAMP(3);  // entry read
-      // far-wing rows, point by point, lanes outside the window masked (interior rows: mask all-true)
-      if (RTX_SC_ABLATE & 4) m_pp = 0u;
+      if (RTX_SC_ABLATE & 4) m_pp = m_ed = 0u;
+      // near-zone rows wholly inside the window: far-wing formula at every point, no lane mask
       while (m_pp) {
         const int r = __builtin_ctz(m_pp);
         m_pp &= m_pp - 1u;
+        float* p = acc + r * 64 + lane;
+        float x0, n0, d0;
+        farwing(u0 + (float)(64 * r), q, x0, n0, d0);
+        p[0] = fmaf(n0, d0, p[0]);
+      }
+      // the <= 2 rows cut by a window edge: lanes outside [lo, hi) masked
+      while (m_ed) {
+        const int r = __builtin_ctz(m_ed);
+        m_ed &= m_ed - 1u;
         float* p = acc + r * 64 + lane;
         const float u = u0 + (float)(64 * r);
         float x0, n0, d0;
@@ -465,7 +475,8 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
     const unsigned m_band = bits(g.z0, g.z1 + 1);
     const unsigned m_far = (RTX_SC_ABLATE & 2) ? 0u : (m_in & ~m_near);           // smooth: Chebyshev nodes of the rows
     const unsigned m_bd = m_reach & m_band;                                       // band rows
-    const unsigned m_pp = ((m_reach & m_near) | (m_reach & ~m_in)) & ~m_band;     // near-zone rows and window edges
+    const unsigned m_pp = m_in & m_near & ~m_band;                                 // near-zone rows wholly inside the window
+    const unsigned m_ed = m_reach & ~m_in & ~m_band;                              // rows cut by a window edge
     const float ub = (float)(ia - qi0);  // integer-valued
     constexpr unsigned ALL_ROWS = (1u << ROWS) - 1u;
     if (RTX_SC_STAMP && __ballot(m_pp == 0xffffffffu)) t_ph[7] += 1;  // (forces the masks, i.e. the record loads, before the stamp)
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
 
     // ---- point-by-point rows: 64-byte entries, drained by the whole wave ---------------------------------------
     {
-      bool emit = !(RTX_SC_ABLATE & 8) && (m_pp | m_bd) != 0u;
+      bool emit = !(RTX_SC_ABLATE & 8) && (m_pp | m_ed | m_bd) != 0u;
       unsigned long long eb = __ballot(emit);
       while (eb) {
         const int room = SC_ENT_CAP - n_ent;
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
           d[0] = f0;
           d[1] = f1;
           d[2] = make_float4(ub, (float)(qlo - qi0), (float)(qhi - qi0), qzw > 0 ? (float)qzw : -1.0f);
-          d[3] = make_float4(__int_as_float((int)m_pp), __int_as_float((int)m_bd), __int_as_float(slot), 0.f);
+          d[3] = make_float4(__int_as_float((int)m_pp), __int_as_float((int)m_bd), __int_as_float(slot), __int_as_float((int)m_ed));
           emit = false;
         }
         const int cnt = __popcll(eb);

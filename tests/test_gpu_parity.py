@@ -450,9 +450,10 @@ def test_full_c3_width_properties():
     OD1 = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
     OD2 = engine.optical_depths(lines, sh, a["Ts"], a["Ps"], a["PLs"], 2.0 * a["MFs_VAL"], a["MFs_ID"])
     ref_slice = OD[:, sh.offset:sh.offset + sh.n]
-    # an unaligned shard regroups the fp32 sums per tile: last-bit differences only
+    # an unaligned shard puts the rows elsewhere: other fp32 summation groups, and a point that was evaluated directly in
+    # one tiling is interpolated from row nodes in the other (<= 2.3e-7 of a line's own contribution with a 2-row near zone)
     d = ((OD1 - ref_slice).abs() / ref_slice.abs().clamp_min(1e-3 * float(ref_slice.max()))).max()
-    assert float(d) <= 1e-6, float(d)
+    assert float(d) <= 3e-6, float(d)
     # a shard that starts and ends on tile boundaries reproduces the full grid's tiles, hence its bits
     from radtxfr_amd import _lib
     tp = int(_lib.load().rtx_voigt_tile_points())

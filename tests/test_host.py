@@ -277,13 +277,15 @@ def test_chebyshev_tables_match_generator_and_error_bounds():
 
     p = np.arange(64.0)
     W = lagr(nodes, p)
-    # row level: centre >= 3 full rows + 1 point before the row start (SC_NEAR = 3)
+    # row level: centre >= 2 full rows + 1 point before the row start (RTX_SC_NEAR = 2 since round 2; 3 gave 1.4e-8)
+    src = open(os.path.join(ROOT, "radtxfr_amd", "csrc", "rtx_voigt_scatter.hip")).read()
+    assert re.search(r"#define RTX_SC_NEAR 2\b", src)
     worst = 0.0
     for g in (0.5, 5.0, 30.0, 100.0):
-        for d0 in (193.0, 225.0, 256.0):
+        for d0 in (129.0, 161.0, 192.0):
             f = lambda t: 1.0 / ((t + d0) ** 2 + g * g)
             worst = max(worst, np.max(np.abs(W @ f(nodes) - f(p)) / f(p)))
-    assert worst < 2e-8, worst
+    assert worst < 3e-7, worst
     # tile level (20 rows): pole >= 193 points outside the tile, through both stages
     rows, nt = 20, 32
     tile = 64 * rows
