@@ -42,7 +42,7 @@
 #define RTX_SC_ASYM 1
 #endif
 #ifndef RTX_SC_ROWS
-#define RTX_SC_ROWS 20  // rows of 64 points per tile: 1280 points, 5 KiB of LDS per wave copy (measured: 16 -> 5.63 ms, 20 -> 5.35, 24 -> 5.42, 32 -> 6.1)
+#define RTX_SC_ROWS 16  // rows of 64 points per tile (1024 points, 4 KiB of LDS per wave copy). Round 2, after the tile level went: 8 -> 2.38 ms, 10 -> 2.38, 12 -> 2.32, 14 -> 2.29, 16 -> 2.24, 18 -> 2.34, 20 -> 2.32 (C3, prologue + line-sum)
 #endif
 #ifndef RTX_SC_NEAR
 #define RTX_SC_NEAR 2  // rows either side of the centre row that stay point-by-point in the nodal kernel (3: 2.48 ms, interpolation error <= 1.4e-8 of a line's own contribution; 2: 2.34 ms, <= 2.3e-7)
