@@ -1123,3 +1123,77 @@ def test_fused_entry_equals_three_calls():
         torch.cuda.synchronize()
         assert torch.equal(run.OD, OD) and torch.equal(t2, tau) and torch.equal(u2, Lu) and torch.equal(d2, Ld)
         lines.close()
+
+
+# ----------------------------------------------------------------------- C4 / C5 at FULL size, sampled against the oracle
+def _mako_span_tud():
+    """tau, L-up, L-down of the engine on the MAKO span of the C3 grid (755-1325 cm^-1 at 0.001 cm^-1: 570 000 points, a
+    shard of the 5.5 M-point axis), 32 layers, mixing ratios x 3e-3 so that the span has windows and bands."""
+    import torch
+    from radtxfr_amd import engine
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    g_full = engine.Grid(500.0, 6000.0, 5500000)
+    i0, i1 = int((755.0 - 500.0) / g_full.step), int((1325.0 - 500.0) / g_full.step)
+    grid = g_full.shard(i0, i1 - i0)
+    a = synthetic.c3_atmosphere(32)
+    lines = engine.LineTable(synthetic.subset_table(full, 740.0, 1340.0))
+    run = engine.TudRunner(lines, grid, a["Zs"], n_layers=32)
+    tau, Lu, Ld = run.run(a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"] * 3e-3, a["MFs_ID"])
+    torch.cuda.synchronize()
+    out = grid, tau[0].clone(), Lu[0].clone(), Ld.clone()
+    lines.close()
+    return out
+
+
+def test_c4_full_size_sampled_columns_vs_oracle(rt):
+    """Config C4 at BASELINE.json's full size -- 2000 emissivities x 570 000 monochromatic points x 128 MAKO bands -- on the
+    engine's own TUD of that span: 24 of the 2000 columns are checked against the oracle evaluated at the full spectral
+    size (np.interp of the knots, compute_LWIR_apparent_radiance, the reference's ILS); the streaming pipeline and the fused
+    one must both match, and agree with each other on all 2000 columns."""
+    import torch
+    from radtxfr_amd import sensor
+    grid, tau, La, Ld = _mako_span_tud()
+    X = grid.axis()
+    t64, a64, d64 = (v.double().cpu().numpy() for v in (tau, La, Ld))
+    assert 0.02 < np.median(t64) < 0.999 and t64.min() < 0.05 and t64.max() > 0.5
+    Xe, em = synthetic.synth_emissivities(n_emis=2000)
+    em_d = torch.as_tensor(em.astype(np.float32), device="cuda")
+    xo, Lb = sensor.band_radiance(grid, tau, La, Ld, Xe, em_d, 287.87)
+    xf, Lf = sensor.band_radiance_fused(grid, tau, La, Ld, Xe, em_d, 287.87)
+    assert Lb.shape == Lf.shape == (xo.size, 2000) and xo.size >= 126 and np.array_equal(xo, xf)
+    assert rel_err(Lf.cpu().numpy(), Lb.cpu().numpy()) <= 3e-6
+    cols = np.arange(7, 2000, 83)
+    em_ref = np.stack([np.interp(X, Xe, em[:, k].astype(np.float32).astype(np.float64)) for k in cols], axis=1)
+    L_ref = ref.compute_LWIR_apparent_radiance(X, em_ref, np.array([287.87]), t64[:, None], a64[:, None], d64[:, None])[:, :, 0]
+    xr, Lb_ref = ref.ILS_MAKO(X, L_ref)
+    assert np.array_equal(xo, xr)
+    assert rel_err(Lb.cpu().numpy()[:, cols], Lb_ref) <= TOL_L
+    assert rel_err(Lf.cpu().numpy()[:, cols], Lb_ref) <= TOL_L
+
+
+def test_c5_full_size_sampled_pixels_vs_oracle(rt):
+    """Config C5 at full size -- 256 x 256 pixels x 256 MAKO bands (resFactor 2) from 570 000 monochromatic points -- on the
+    engine's own TUD of the span: 64 of the 65 536 pixels are checked against the oracle, which forms each pixel's
+    monochromatic spectrum (its emissivity mixture, its surface temperature; LWIR_HSI_Generator.py:151-167) and runs the
+    reference's ILS on it at the full spectral size."""
+    import torch
+    from radtxfr_amd import sensor
+    grid, tau, La, Ld = _mako_span_tud()
+    X = grid.axis()
+    t64, a64, d64 = (v.double().cpu().numpy() for v in (tau, La, Ld))
+    Xe, em = synthetic.synth_emissivities(n_emis=2000)
+    sc = synthetic.synth_scene()  # 65 536 pixels, 2-of-6 mixtures, T = 287.87 + 3 N(0,1)
+    E = em[:, sc["end_idx"]].astype(np.float32)
+    dev = torch.device("cuda")
+    xo, cube = sensor.hsi_cube(grid, tau, La, Ld, Xe, torch.as_tensor(E, device=dev), torch.as_tensor(sc["kidx"], device=dev),
+                               torch.as_tensor(sc["frac"].astype(np.float32), device=dev), torch.as_tensor(sc["T"], device=dev),
+                               resFactor=2)
+    assert cube.shape == (xo.size, 256 * 256) and xo.size >= 252 and bool(torch.isfinite(cube).all())
+    pix = np.arange(11, 65536, 1040)[:64]
+    E_hi = np.stack([np.interp(X, Xe, E[:, k].astype(np.float64)) for k in range(E.shape[1])], axis=1)   # [nX][6]
+    frac = sc["frac"].astype(np.float32).astype(np.float64)[pix]
+    em_p = np.einsum("pm,xpm->xp", frac, E_hi[:, sc["kidx"][pix]])                                      # [nX][64]
+    L = t64[:, None] * (em_p * ref.planckian(X, sc["T"][pix]) + (1 - em_p) * d64[:, None]) + a64[:, None]
+    xr, Lr = ref.ILS_MAKO(X, L, resFactor=2)
+    assert np.array_equal(xo, xr)
+    assert rel_err(cube.cpu().numpy()[:, pix], Lr) <= TOL_L
