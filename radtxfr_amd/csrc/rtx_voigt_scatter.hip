@@ -283,16 +283,11 @@ __device__ __forceinline__ void store_tile(const ScArgs& a, const float (*s_acc)
 }
 
 template <bool CORE64>
-__global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
+__device__ __forceinline__ void scatter_tile(const ScArgs& a, float (*s_acc)[64 * RTX_SC_ROWS], int* s_touched, int b, int k) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
-  __shared__ float s_acc[4][TILE];  // one private tile per wave
-
-  const int b = blockIdx.x;
   const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
   if (tile >= a.n_tiles) return;
-  const int k = blockIdx.y;
-  if (CORE64 && a.smally[k] == 0) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const long long n = a.g.n;
@@ -318,14 +313,33 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
   __syncthreads();  // every wave's tile is complete
 
   if (CORE64) {  // did any wave add anything? (uniform per workgroup through LDS)
-    __shared__ int s_touched;
-    if (threadIdx.x == 0) s_touched = 0;
+    if (threadIdx.x == 0) *s_touched = 0;
     __syncthreads();
-    if (touched && lane == 0) s_touched = 1;
+    if (touched && lane == 0) *s_touched = 1;
     __syncthreads();
-    if (!s_touched) return;
+    if (!*s_touched) return;
   }
   store_tile<CORE64, false>(a, s_acc, nullptr, k, ia, ib, wave, lane);
+}
+
+// CORE64 = false: one workgroup per tile slot. CORE64 = true (the pass that only matters for Doppler-dominated lines): a
+// grid-stride loop over the tile slots with 1/16 of the workgroups -- when a layer has no such line (every layer of C3)
+// each workgroup returns at once, and launching one per tile just to do that cost 30 us per step. The stride is a
+// multiple of 8, so a workgroup's slots stay on its XCD (xcd_tile).
+template <bool CORE64>
+__global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
+  __shared__ float s_acc[4][64 * RTX_SC_ROWS];  // one private tile per wave
+  __shared__ int s_touched;
+  const int k = blockIdx.y;
+  if (CORE64) {
+    if (a.smally[k] == 0) return;
+    for (int b = blockIdx.x; b < 8 * a.tiles_per_xcd; b += gridDim.x) {
+      scatter_tile<true>(a, s_acc, &s_touched, b, k);
+      __syncthreads();  // the tile copies are reused by the next slot
+    }
+  } else {
+    scatter_tile<false>(a, s_acc, &s_touched, blockIdx.x, k);
+  }
 }
 
 // ---- main pass: far rows at Chebyshev nodes, near rows point by point --------------------------------------------------
@@ -650,7 +664,7 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
             h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
   }
 #endif
-  hipLaunchKernelGGL((voigt_scatter_kernel<true>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((voigt_scatter_kernel<true>), dim3(8 * ((a.tiles_per_xcd + 15) / 16), n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }
