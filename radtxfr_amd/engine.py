@@ -199,23 +199,38 @@ def species_factors(species, T_layers, partitionFunction=None, weight=None):
     nS, nL = len(species), len(T_layers)
     q = np.ones((nS, nL))
     mass = np.ones(nS)
-    wz = None if weight is None else ~np.any(np.broadcast_to(np.asarray(weight, dtype=np.float64), (nS, nL)) != 0.0, axis=1)
-    use = [s for s, mi in enumerate(species) if mi != (0, 0) and not (wz is not None and wz[s])]
+    if weight is None:
+        use = [s for s, mi in enumerate(species) if mi != (0, 0)]
+    else:
+        live = np.asarray(weight).reshape(nS, -1).any(axis=1)
+        use = [s for s, mi in enumerate(species) if mi != (0, 0) and live[s]]
     if not use:
         return q, mass
-    for s in use:
-        mass[s] = tips.molecularMass(*species[s])
     if partitionFunction is None or partitionFunction is tips.PYTIPS:
         # default TIPS-2011: all (species, layer) pairs in one vectorised pass, plus Q(Tref) as an extra column
-        Q = tips.partition_sums([species[s] for s in use], np.concatenate([np.asarray(T_layers, dtype=np.float64), [TREF]]))
+        key = tuple(species[s] for s in use)
+        plan = _TIPS_PLANS.get(key)
+        if plan is None:
+            if len(_TIPS_PLANS) > 32:
+                _TIPS_PLANS.clear()
+            plan = _TIPS_PLANS[key] = (tips.PartitionPlan(key), np.array([tips.molecularMass(*mi) for mi in key]))
+        Tq = np.empty(nL + 1)
+        Tq[:nL] = T_layers
+        Tq[nL] = TREF
+        Q = plan[0](Tq)
         q[use] = Q[:, -1:] / Q[:, :-1]
+        mass[use] = plan[1]
     else:
         for s in use:
             m, i = species[s]
+            mass[s] = tips.molecularMass(m, i)
             qref = partitionFunction(m, i, TREF)
             for k, T in enumerate(T_layers):
                 q[s, k] = qref / partitionFunction(m, i, float(T))
     return q, mass
+
+
+_TIPS_PLANS = {}
 
 
 def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air=1.0, dil_self=0.0, omega_wing=0.0,

@@ -69,6 +69,58 @@ def partition_sum(M, I, T):
 PYTIPS = partition_sum
 
 
+class PartitionPlan:
+    """partition_sums for a FIXED species list: the table rows are stacked once and the Lagrange denominators -- products
+    of differences of table nodes, which are exact multiples of the uniform 25 K spacing -- are constants, so a call is
+    ~25 NumPy operations on [4][nT] / [nS][nT] arrays. Same operations in the same order as the scalar routine for every
+    temperature inside the table's 4-point range: bit-identical (tests/test_host.py); other temperatures take
+    partition_sums()."""
+
+    def __init__(self, species):
+        t = _tab()
+        self.species = [(int(m), int(i)) for m, i in species]
+        self.A = t["tdat"]
+        rows = []
+        for key in self.species:
+            if key not in t["q"] or not np.isfinite(t["q"][key][0]):
+                raise Exception("TIPS: no data for M,I = %d,%d." % key)
+            rows.append(t["q"][key])
+        self.B = np.stack(rows) if rows else np.zeros((0, self.A.size))
+        A = self.A
+        h = np.diff(A)
+        self.uniform = bool(np.all(h == h[0]))
+        if self.uniform:
+            a = A[:4]
+            self.den = [float(np.prod([1.0] + [a[j] - a[m] for m in range(4) if m != j])) for j in range(4)]
+            # the scalar routine multiplies den factor by factor starting from 1.0: exact here, every factor is a multiple of h
+            for j in range(4):
+                d = 1.0
+                for m in range(4):
+                    if m != j:
+                        d = d * (a[j] - a[m])
+                assert d == self.den[j]
+        self._k4 = np.arange(4)[:, None]
+
+    def __call__(self, T):
+        T = np.atleast_1d(np.asarray(T, dtype=np.float64))
+        A, npt = self.A, self.A.size
+        if T.size and (T.min() < 70.0 or T.max() > 3000.0):
+            raise Exception("TIPS: T must be between 70K and 3000K.")
+        I1 = np.searchsorted(A[1:], T, side="left") + 2
+        if not self.uniform or I1.min() < 3 or I1.max() >= npt:
+            return partition_sums(self.species, T)
+        idx = (I1 - 3)[None, :] + self._k4            # nodes J-2 .. J+1 with J = I1 - 1
+        d0, d1, d2, d3 = T - A[idx]                   # [4][nT] -> rows
+        den = self.den
+        Bn = self.B[:, idx]                           # [nS][4][nT]
+        p01 = d0 * d1
+        out = (((d1 * d2) * d3) / den[0]) * Bn[:, 0] + 0.0
+        out = out + (((d0 * d2) * d3) / den[1]) * Bn[:, 1]
+        out = out + ((p01 * d3) / den[2]) * Bn[:, 2]
+        out = out + ((p01 * d2) / den[3]) * Bn[:, 3]
+        return out
+
+
 def partition_sums(species, T):
     """Q[s][k] = partition_sum(*species[s], T[k]) for all species and temperatures at once: the same 3-/4-point
     Lagrange arithmetic in the same order (bit-identical to the scalar routine, tests/test_host.py), as a few dozen

@@ -238,6 +238,10 @@ def test_vectorised_tips_is_bit_identical_to_the_scalar_routine():
     assert np.array_equal(tips.partition_sums(species, T), want)
     mid = rng.uniform(120.0, 2900.0, 64)  # fast path: every temperature inside the table
     assert np.array_equal(tips.partition_sums(species, mid), np.array([[tips.partition_sum(m, i, t) for t in mid] for m, i in species]))
+    plan = tips.PartitionPlan(species)  # fixed species list, constant Lagrange denominators: what engine.species_factors uses
+    assert np.array_equal(plan(T), want) and np.array_equal(plan(mid), tips.partition_sums(species, mid))
+    with pytest.raises(Exception):
+        plan(np.array([250.0, 3000.1]))
     with pytest.raises(Exception):
         tips.partition_sums(species, np.array([250.0, 69.9]))
     with pytest.raises(Exception):

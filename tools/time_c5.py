@@ -35,3 +35,22 @@ ms = float(np.median(t))
 print(f"C5 cube {tuple(cube.shape)} from nX={grid.n}: {ms:.3f} ms (incl. host-side band set-up) -> "
       f"{cube.numel()/ms/1e-3:.3e} band*pixel values/s, {grid.n*cube.shape[1]/ms/1e-3:.3e} equivalent wavenumber*pixel points/s; "
       f"finite {bool(torch.isfinite(cube).all())} checksum {float(cube.double().sum()):.6e}")
+
+# ---- end to end (round 2): line table + atmosphere -> TUD on the MAKO span -> cube, the driver the 8-GPU run uses
+from radtxfr_amd import dist as rdist
+import time
+table = synthetic.subset_table(synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0), 740.0, 1340.0)
+a = synthetic.c3_atmosphere(32)
+lines = engine.LineTable(table)
+te = []
+for it in range(args.reps + 1):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    xo2, cube2 = rdist.hsi_cube_from_atmosphere(755.0, 1325.0, 0.001, lines, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"] * 3e-3, a["MFs_ID"],
+                                                Xe, E, kidx, frac, T, resFactor=2)
+    torch.cuda.synchronize()
+    if it:
+        te.append((time.perf_counter() - t0) * 1e3)
+print(f"C5 end to end on one GPU (dist.hsi_cube_from_atmosphere: prologue + line-sum + TUD on 570 000 wavenumbers x 32 layers, band moments, "
+      f"pixel cube {tuple(cube2.shape)}): {np.median(te):.2f} ms wall per scene; finite {bool(torch.isfinite(cube2).all())} checksum {float(cube2.double().sum()):.6e}")
+lines.close()
