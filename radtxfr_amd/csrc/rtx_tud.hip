@@ -375,9 +375,15 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
           } else {
 #pragma unroll
             for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
+              // per lane: thin through the emissivity, L + e (B - L); thick through the transmittance, B - t (B - L) (each
+              // form cancels in the other regime). Branch-free: one shared B - L, selects on the factor and on the base --
+              // the same bits as the two fmaf forms (fl(B - L) = -fl(L - B)), without the exec-mask branches the ternary
+              // of whole expressions compiled to.
               const float y = od * cth[q];
-              // per lane: thin through the emissivity, thick through the transmittance (each form cancels in the other regime)
-              L[q] = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - L[q], L[q]) : fmaf(__builtin_amdgcn_exp2f(y), L[q] - B, B);
+              const float d = B - L[q];
+              const bool thin_lane = y > -TUD_THIN_Y;
+              const float w = thin_lane ? em_thin(y) : -__builtin_amdgcn_exp2f(y);
+              L[q] = fmaf(w, d, thin_lane ? L[q] : B);
             }
           }
         }
