@@ -369,7 +369,11 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 // rows (10.6 ms: the LDS float atomic is several times slower than the plain pair), row ownership -- each wave owns rows
 // w, w+4, ... with register accumulators, the entries of all four waves shared through LDS behind two barriers per round,
 // no private tile copies (2.68: the point-by-point rows are bound by their own arithmetic, ~41 SIMD cycles per row
-// against a 34-cycle issue cost, not by the LDS round trip, and the shared lists cost more than the copies did).
+// against a 34-cycle issue cost, not by the LDS round trip, and the shared lists cost more than the copies did), the tile
+// level rebuilt on 16-row tiles with a coalesced (transposed) matrix (2.29 vs 2.28: no gain), and a tree of segment levels --
+// lines two segment lengths away evaluated at 8 nodes per 16-, 8- or 4-row segment, a third of all (line, tile) pairs, 1.5x
+// fewer node evaluations, same 2.3e-7 accuracy -- with its three extra compaction passes (2.44 vs 2.24: a pass's fixed cost,
+// one ds_permute + nine ds_bpermute per group of 8 lines, outweighs the evaluations it saves).
 #ifndef RTX_SC_WAVES
 #define RTX_SC_WAVES 6
 #endif
