@@ -267,19 +267,31 @@ def voigt_sum(lines, grid, T, p_atm, weight, out_f32=None, out_f64=None, dil_air
     return out_f32, out_f64
 
 
+_MF_COLUMNS = {}
+
+
 def layer_weights_od(species, T, P_pa, PL_km, MF_VAL, MF_ID):
-    """weight[nS][nL] for optical depth: n(p,T) * x_m * PL*1e5 for the line's molecule."""
+    """weight[nS][nL] for optical depth: n(p,T) * x_m * PL*1e5 for the line's molecule.
+    `xs * (ppmv*1e-6) * PL * 1e5` with xs carrying factor = volumeConcentration (HITRAN_units=False); the same operations in
+    the same order for every species (one [nS][nL] pass: the species -> mixing-ratio column map is cached)."""
     T = np.asarray(T, dtype=np.float64)
     p_atm = np.asarray(P_pa, dtype=np.float64) / 101325.0
     PL = np.asarray(PL_km, dtype=np.float64)
     MF_VAL = np.asarray(MF_VAL, dtype=np.float64).reshape(T.size, -1)
-    ids = [int(v) for v in np.asarray(MF_ID).ravel()]
-    w = np.zeros((len(species), T.size))
+    ids = tuple(int(v) for v in np.asarray(MF_ID).ravel())
+    key = (tuple(species), ids)
+    m = _MF_COLUMNS.get(key)
+    if m is None:
+        if len(_MF_COLUMNS) > 64:
+            _MF_COLUMNS.clear()
+        col = np.array([ids.index(mm) if mm in ids else 0 for mm, _ in species], dtype=np.int64)
+        live = np.array([mm in ids for mm, _ in species], dtype=bool)
+        m = _MF_COLUMNS[key] = (col, live, bool(live.all()))
+    col, live, all_live = m
     nvol = volumeConcentration(p_atm, T)
-    for s, (m, _) in enumerate(species):
-        if m in ids:
-            # `xs * (ppmv*1e-6) * PL * 1e5` with xs carrying factor = volumeConcentration (HITRAN_units=False)
-            w[s] = nvol * (MF_VAL[:, ids.index(m)] * 1e-6) * PL * 1e5
+    w = nvol * (MF_VAL.T[col] * 1e-6) * PL * 1e5 if len(species) else np.zeros((0, T.size))
+    if not all_live:
+        w[~live] = 0.0
     return w, p_atm
 
 
