@@ -177,13 +177,23 @@ struct TudArgs {
 // A layer's emissivity (1 - t) is what weights its Planck radiance in L <- t L + (1 - t) B; forming it as 1 - fl(t)
 // from v_exp_f32 loses everything once t is within a few ulp of 1 (an optically thin layer: the LWIR window),
 // and the error of the accumulated radiance then reaches 1e-5..1e-4 of a thin path's radiance. So:
-//   |y| <  1/8 : 1 - 2^y = -y*ln2*(1 + z/2 + z^2/6 + z^3/24 + z^4/120), z = y ln2   (truncation 7e-9)
-//   |y| >= 1/8 : 1 - v_exp_f32(y)                                                    (relative error <= 7e-7)
-#define TUD_THIN_Y 0.125f
+//   |y| <  1/16 : 1 - 2^y = -y*ln2*(1 + z/2 + z^2/6 + z^3/24), z = y ln2            (truncation 2.9e-8)
+//   |y| >= 1/16 : 1 - v_exp_f32(y)                                                    (relative error <= 1.4e-6)
+// (round 1: degree 5 below 1/8, 7e-9 / 7e-7; one operation more per stream and layer: TUD_THIN_DEG5 / TUD_THIN_Y)
+#ifndef TUD_THIN_Y
+#define TUD_THIN_Y 0.0625f
+#endif
+#ifndef TUD_THIN_DEG5
+#define TUD_THIN_DEG5 0  /* 1: degree-5 emissivity polynomial (use with TUD_THIN_Y 0.125f) */
+#endif
 #define TUD_OPAQUE_Y 26.0f
 __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
+#if TUD_THIN_DEG5
   const float q = fmaf(fmaf(fmaf(fmaf(1.3333558146e-3f, y, 9.6181291076e-3f), y, 5.5504108665e-2f), y, 2.4022650696e-1f), y,
                        6.9314718056e-1f);  // ln2^5/120, ln2^4/24, ln2^3/6, ln2^2/2, ln2
+#else
+  const float q = fmaf(fmaf(fmaf(9.6181291076e-3f, y, 5.5504108665e-2f), y, 2.4022650696e-1f), y, 6.9314718056e-1f);
+#endif
   return -y * q;
 }
 
@@ -335,11 +345,18 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
         // layer, shared by all streams): 5 VALU per stream instead of forming y and running em_thin (6)
         const float o2 = od * od;
         const float A1 = -6.9314718056e-1f * od, A2 = -2.4022650696e-1f * o2, A3 = -5.5504108665e-2f * (o2 * od);
-        const float A4 = -9.6181291076e-3f * (o2 * o2), A5 = -1.3333558146e-3f * (o2 * o2 * od);
+        const float A4 = -9.6181291076e-3f * (o2 * o2);
+#if TUD_THIN_DEG5
+        const float A5 = -1.3333558146e-3f * (o2 * o2 * od);
+#endif
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
           const float c = cth[q];
+#if TUD_THIN_DEG5
           const float e = c * fmaf(c, fmaf(c, fmaf(c, fmaf(c, A5, A4), A3), A2), A1);
+#else
+          const float e = c * fmaf(c, fmaf(c, fmaf(c, A4, A3), A2), A1);
+#endif
           L[q] = fmaf(e, B - L[q], L[q]);
         }
       } else {
@@ -350,7 +367,10 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
         // form; all lanes thin for its most oblique one -> emissivity polynomial; else both forms and a per-lane select.
         const float o2 = od * od;
         const float A1 = -6.9314718056e-1f * od, A2 = -2.4022650696e-1f * o2, A3 = -5.5504108665e-2f * (o2 * od);
-        const float A4 = -9.6181291076e-3f * (o2 * o2), A5 = -1.3333558146e-3f * (o2 * o2 * od);
+        const float A4 = -9.6181291076e-3f * (o2 * o2);
+#if TUD_THIN_DEG5
+        const float A5 = -1.3333558146e-3f * (o2 * o2 * od);
+#endif
 #pragma unroll
         for (int q0 = 0; q0 < NA; q0 += 4) {
           // |c| ascends with the stream index (pads repeat the last stream): the block's extremes are its end streams,
@@ -369,7 +389,11 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
 #pragma unroll
             for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
               const float c = cth[q];
+#if TUD_THIN_DEG5
               const float e = c * fmaf(c, fmaf(c, fmaf(c, fmaf(c, A5, A4), A3), A2), A1);
+#else
+              const float e = c * fmaf(c, fmaf(c, fmaf(c, A4, A3), A2), A1);
+#endif
               L[q] = fmaf(e, B - L[q], L[q]);
             }
           } else {
