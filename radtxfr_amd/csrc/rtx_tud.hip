@@ -207,6 +207,9 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 //   mixed : per lane, the thin form where |y| < 1/8 and the thick form elsewhere
 // OD is read once per block of streams, coalesced along the wavenumber axis.
 #define TUD_STAGE 8
+#ifndef TUD_ILP
+#define TUD_ILP 8  // streams advanced together, step by step, in the all-thick / all-thin layers
+#endif
 template <int NA>
 __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots: no barrier
@@ -335,10 +338,21 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) L[q] = B;
       } else if (__ballot(thick) == ~0ull) {
+        // step-major over blocks of TUD_ILP streams, pinned with scheduling barriers: left to itself the compiler runs the
+        // streams' 4-operation chains one after the other (s_nop between dependent packed operations), so a wave never has
+        // two independent vector instructions to issue; here every step offers TUD_ILP of them
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-          const float t = __builtin_amdgcn_exp2f(od * cth[q]);
-          L[q] = fmaf(t, L[q] - B, B);
+        for (int q0 = 0; q0 < NA; q0 += TUD_ILP) {
+          float t[TUD_ILP];
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) t[i] = od * cth[q0 + i];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) t[i] = __builtin_amdgcn_exp2f(t[i]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) L[q0 + i] = fmaf(t[i], L[q0 + i] - B, B);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else if (__ballot(thin) == ~0ull) {
         // 1 - 2^(OD c) as a polynomial in the stream's c with per-lane coefficients A_k = -q_k OD^k (5 multiplies per
@@ -350,14 +364,31 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
         const float A5 = -1.3333558146e-3f * (o2 * o2 * od);
 #endif
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-          const float c = cth[q];
+        for (int q0 = 0; q0 < NA; q0 += TUD_ILP) {  // step-major, as above
+          float e[TUD_ILP];
 #if TUD_THIN_DEG5
-          const float e = c * fmaf(c, fmaf(c, fmaf(c, fmaf(c, A5, A4), A3), A2), A1);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) e[i] = fmaf(cth[q0 + i], A5, A4);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) e[i] = fmaf(cth[q0 + i], e[i], A3);
 #else
-          const float e = c * fmaf(c, fmaf(c, fmaf(c, A4, A3), A2), A1);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) e[i] = fmaf(cth[q0 + i], A4, A3);
 #endif
-          L[q] = fmaf(e, B - L[q], L[q]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) e[i] = fmaf(cth[q0 + i], e[i], A2);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) e[i] = fmaf(cth[q0 + i], e[i], A1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) e[i] = cth[q0 + i] * e[i];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < TUD_ILP; ++i) if (q0 + i < NA) L[q0 + i] = fmaf(e[i], B - L[q0 + i], L[q0 + i]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
         // Mixed layer: neither form holds for every lane AND every stream. The slant factors span 1 .. 19, so a layer
@@ -379,37 +410,60 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
           const int q1 = q0 + 3 < NA ? q0 + 3 : NA - 1;
           const bool blk_thick = __ballot(od * -cth[q0] >= TUD_THIN_Y) == ~0ull;
           const bool blk_thin = __ballot(od * -cth[q1] < TUD_THIN_Y) == ~0ull;
+          const int nq = q0 + 4 < NA ? 4 : NA - q0;  // streams of this block (compile-time after unrolling)
+          float w[4];
+          // the block's 4 streams advance together, step by step (scheduling barriers pin the order: four independent
+          // instructions per step instead of four serial chains)
           if (blk_thick) {
 #pragma unroll
-            for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
-              const float t = __builtin_amdgcn_exp2f(od * cth[q]);
-              L[q] = fmaf(t, L[q] - B, B);
-            }
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = od * cth[q0 + i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = __builtin_amdgcn_exp2f(w[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) L[q0 + i] = fmaf(w[i], L[q0 + i] - B, B);
           } else if (blk_thin) {
-#pragma unroll
-            for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
-              const float c = cth[q];
 #if TUD_THIN_DEG5
-              const float e = c * fmaf(c, fmaf(c, fmaf(c, fmaf(c, A5, A4), A3), A2), A1);
-#else
-              const float e = c * fmaf(c, fmaf(c, fmaf(c, A4, A3), A2), A1);
-#endif
-              L[q] = fmaf(e, B - L[q], L[q]);
-            }
-          } else {
 #pragma unroll
-            for (int q = q0; q < (q0 + 4 < NA ? q0 + 4 : NA); ++q) {
-              // per lane: thin through the emissivity, L + e (B - L); thick through the transmittance, B - t (B - L) (each
-              // form cancels in the other regime). Branch-free: one shared B - L, selects on the factor and on the base --
-              // the same bits as the two fmaf forms (fl(B - L) = -fl(L - B)), without the exec-mask branches the ternary
-              // of whole expressions compiled to.
-              const float y = od * cth[q];
-              const float d = B - L[q];
-              const bool thin_lane = y > -TUD_THIN_Y;
-              const float w = thin_lane ? em_thin(y) : -__builtin_amdgcn_exp2f(y);
-              L[q] = fmaf(w, d, thin_lane ? L[q] : B);
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = fmaf(cth[q0 + i], A5, A4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = fmaf(cth[q0 + i], w[i], A3);
+#else
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = fmaf(cth[q0 + i], A4, A3);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = fmaf(cth[q0 + i], w[i], A2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = fmaf(cth[q0 + i], w[i], A1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) w[i] = cth[q0 + i] * w[i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) L[q0 + i] = fmaf(w[i], B - L[q0 + i], L[q0 + i]);
+          } else {
+            // per lane: thin through the emissivity, L + e (B - L); thick through the transmittance, B - t (B - L) (each form
+            // cancels in the other regime). Branch-free: one shared B - L, selects on the factor and on the base -- the same
+            // bits as the two fmaf forms (fl(B - L) = -fl(L - B)).
+            float y[4], t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) y[i] = od * cth[q0 + i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) { t[i] = __builtin_amdgcn_exp2f(y[i]); w[i] = em_thin(y[i]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < nq) {
+              const bool thin_lane = y[i] > -TUD_THIN_Y;
+              L[q0 + i] = fmaf(thin_lane ? w[i] : -t[i], B - L[q0 + i], thin_lane ? L[q0 + i] : B);
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
