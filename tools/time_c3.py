@@ -37,16 +37,4 @@ for it in range(args.reps + 2):
 print("%s tile=%d  prep+voigt %.3f ms (min %.3f)  tud %.3f ms  checksum OD %.6e tau %.6e Lu %.6e Ld %.6e" % (
     os.path.basename(_lib.LIB_PATH), lib.rtx_voigt_tile_points(), np.median(tv), np.min(tv), np.median(tt),
     float(OD.double().sum()), float(tau.double().sum()), float(Lu.double().sum()), float(Ld.double().sum())))
-
-# ---- drop-in call, host arrays in and out (PCIe + host conversion inclusive) --------------------------------
-if args.n == 5500000 and args.layers == 32:
-    import time
-    from radtxfr_amd import radiative_transfer as rt
-    kw = dict(DVOUT=0.001, line_table=full, Altitudes=np.asarray([500]), **atm)
-    rt.compute_TUD(500.0, 6000.0, **kw)  # first call uploads the table and allocates the plan
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    X, tau_h, Lu_h, Ld_h = rt.compute_TUD(500.0, 6000.0, **kw)
-    dt = time.perf_counter() - t0
-    print("drop-in rt.compute_TUD(500, 6000, DVOUT=0.001) -> NumPy float64 (X, tau, Lu, Ld): %.1f ms per call "
-          "(%.3e points/s including device->host copies and float64 conversion)" % (dt * 1e3, args.n * args.layers / dt))
+# (the drop-in rt.compute_TUD / compute_TUD_batch calls are timed by tools/time_dropin.py)
