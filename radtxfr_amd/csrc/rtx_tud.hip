@@ -15,6 +15,7 @@
 // and only the fractional part goes through v_exp_f32. Layer transmittances exp(-OD/cos) are
 // fp32 (arguments matter only while OD < ~20).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rtx_common.h"
@@ -171,6 +172,9 @@ struct TudArgs {
   float mu[TUD_MAX_MU];
   unsigned int mask[TUD_MAX_ALT][TUD_MAX_LAYERS / 32];
   int count[TUD_MAX_ALT];
+  const double* gtab;                  // angle-summed transmission function G (tud_g_kernel): [g_nint][8] doubles
+  int g_nint;
+  double g0;                           // G(0) = sum of the quadrature weights
 };
 
 // 1 - exp(-OD*sec) = 1 - 2^y (y = OD*c <= 0), accurate to ~1e-7 RELATIVE also when it is tiny.
@@ -207,20 +211,59 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 //   mixed : per lane, the thin form where |y| < 1/8 and the thick form elsewhere
 // OD is read once per block of streams, coalesced along the wavenumber axis.
 #define TUD_STAGE 8
+#ifndef TUD_ABLATE
+#define TUD_ABLATE 0  /* timing experiments: 1 = all-thin layers skip the stream updates, 2 = no Planck evaluation, 4 = no up-path */
+#endif
+#ifndef TUD_CTH_VGPR
+#define TUD_CTH_VGPR 0
+#endif
 #ifndef TUD_ILP
 #define TUD_ILP 8  // streams advanced together, step by step, in the all-thick / all-thin layers
 #endif
-template <int NA>
+// COL: the whole column of a workgroup's 256 wavenumbers is resident in LDS ([n_layers][256] floats, each thread its own
+// slots, so no barrier): every layer's load is issued up front as an LDS-DMA (global_load_lds_dword: no destination
+// registers, n_layers loads in flight per wave instead of 8), and the opaque-slab scan, the further (altitude, slant)
+// pairs and the main pass all read OD from LDS -- HBM is read exactly once. Up to TUD_COL_LAYERS layers (36 KB per
+// workgroup, 4 workgroups per CU); deeper columns (the reference's default 66-layer table) take the chunked form
+// (COL = false: 8 layers at a time through registers, scan by batched global loads).
+#define TUD_COL_LAYERS 36
+template <int NA, bool COL>
 __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
-  __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots: no barrier
+  extern __shared__ float s_od[];  // COL: [n_layers][256]; else [TUD_STAGE][256]
+  float (*s_stage)[256] = reinterpret_cast<float (*)[256]>(s_od);
   const long long i_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i_raw < a.g.n;
   const long long i = live ? i_raw : a.g.n - 1;  // dead lanes shadow the last point: ballots stay wave-wide
   const int nL = a.n_layers;
+  const float* __restrict__ od_col = a.OD + i;
+  if (COL) {
+    float* dst = &s_stage[0][threadIdx.x & ~63u];  // wave-uniform base; the DMA adds lane * 4
+    for (int k = 0; k < nL; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(od_col + (size_t)k * a.ld),
+                                       (__attribute__((address_space(3))) void*)(dst + k * 256), 4, 0, 0);
+  }
   const double x = grid_x(a.g, a.g.offset + i);
   const double x100 = x * 100.0;
   const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
-  const float* __restrict__ od_col = a.OD + i;
+  if (COL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the column has landed (this wave's own slots)
+  auto od_at = [&](int k) -> float { return COL ? s_stage[k][threadIdx.x] : od_col[(size_t)k * a.ld]; };
+  // Per-layer constants without a trip to memory inside the layer loop: lane l keeps 100 c2 log2(e)/T of layers l and
+  // l + 64 and the loop fetches layer k's with two v_readlane (the kernel-argument array indexed by the loop counter was
+  // a scalar load and its wait -- a few hundred exposed cycles -- in every iteration); likewise the first altitude's
+  // layer mask is held in four scalar registers.
+  const int lane_id = threadIdx.x & 63;
+  const double ct_a = a.c2l2e_over_T[lane_id < nL ? lane_id : 0];
+  const double ct_b = COL ? 0.0 : a.c2l2e_over_T[lane_id + 64 < nL ? lane_id + 64 : 0];
+  auto c2l2e_of = [&](int k) -> double {  // k is wave-uniform
+    const double v = (COL || k < 64) ? ct_a : ct_b;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), k & 63);
+    return __hiloint2double(hi, lo);
+  };
+  const unsigned mk0 = a.mask[0][0], mk1 = a.mask[0][1], mk2 = a.mask[0][2], mk3 = a.mask[0][3];
+  auto mask0_bit = [&](int k) -> bool {
+    const unsigned w = k < 32 ? mk0 : k < 64 ? mk1 : k < 96 ? mk2 : mk3;
+    return (w >> (k & 31)) & 1u;
+  };
 
   // ---- every further (altitude, slant factor) pair: transmittance + upwelling bottom-up (:346-356) ----------
   for (int p = 1; p < a.n_alt * a.n_mu; ++p) {
@@ -229,10 +272,10 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
     const float c = a.mu_c[im];
     float s = 0.f, Lu = 0.f;
     for (int k = 0; k < nL; ++k) {
-      const float od = od_col[(size_t)k * a.ld];
+      const float od = od_at(k);
       if ((a.mask[ia][k >> 5] >> (k & 31)) & 1u) s += od;
       if (k < cnt) {
-        const float B = planck_f32(c1x3, x, a.c2l2e_over_T[k]);
+        const float B = planck_f32(c1x3, x, c2l2e_of(k));
         const float y = od * c;
         // t*Lu + (1-t)*B: thin lanes through the emissivity, thick lanes through the transmittance (the other way
         // round each form cancels: L + e (B - L) with e ~ 1, or t (L - B) + B with t ~ 1)
@@ -270,7 +313,23 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   // layers at either end of the column; the layers in between only add their OD to the tau sum. In a window
   // (no such slab) the scan costs one extra pass of loads and adds.
   int k_start = nd - 1;
-  {
+  if (COL) {
+    // a lane's prefix sums only grow, so "every lane opaque at layer k" first holds at the largest of the lanes' own first
+    // crossings: count, per lane, the prefix sums still below the threshold (no ballots, no branches), then one wave maximum
+    float S = 0.f;
+    int below = 0;
+    for (int k = 0; k < nd; ++k) {
+      S += s_stage[k][threadIdx.x];
+      below += (S * a.ang_cmin >= y_opq) ? 0 : 1;
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+      const int o = __shfl_xor(below, sh);
+      below = o > below ? o : below;
+    }
+    below = __builtin_amdgcn_readfirstlane(below);  // every lane holds the maximum: tell the compiler it is wave-uniform
+    k_start = below < nd - 1 ? below : nd - 1;
+  } else {
     float S = 0.f;
     bool found = false;
     // independent loads in flight per step, not one per layer: 2 for the first step (in an absorption band the slab
@@ -298,6 +357,9 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
     for (int q = 0; q < NA; ++q) {
       L[q] = 0.f;
       cth[q] = a.ang_c[a0 + q];  // slots past n_ang_real hold the weight-0 nadir stream
+#if TUD_CTH_VGPR
+      asm volatile("" : "+v"(cth[q]));  // keep the stream constants in vector registers (see TUD_CTH_VGPR)
+#endif
     }
     const float c_min = a.ang_cmin, c_max = a.ang_cmax;  // |c| range over the streams (nadir .. most oblique)
     // OD is fetched TUD_STAGE layers at a time: the loads of the next chunk are issued before the current chunk is
@@ -305,22 +367,33 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
     // the copy that rotates it has to wait for the load) and handed over through the thread's own LDS slots, so the
     // layer loop stays one run-time loop with one copy of the stream code.
     const int k_top = (a0 == 0 ? nL : nd) - 1;
+    constexpr int CHUNK = COL ? TUD_MAX_LAYERS : TUD_STAGE;  // COL: one chunk, nothing to restage
     float nxt[TUD_STAGE];
+    if (!COL) {
 #pragma unroll
-    for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(k_top - t > 0 ? k_top - t : 0) * a.ld];
-    for (int kc = k_top; kc >= 0; kc -= TUD_STAGE) {
+      for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(k_top - t > 0 ? k_top - t : 0) * a.ld];
+    }
+    for (int kc = k_top; kc >= 0; kc -= CHUNK) {
+      if (!COL) {
 #pragma unroll
-      for (int t = 0; t < TUD_STAGE; ++t) s_stage[t][threadIdx.x] = nxt[t];
+        for (int t = 0; t < TUD_STAGE; ++t) s_stage[t][threadIdx.x] = nxt[t];
 #pragma unroll
-      for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(kc - TUD_STAGE - t > 0 ? kc - TUD_STAGE - t : 0) * a.ld];
-      const int k_lo = kc - TUD_STAGE + 1 > 0 ? kc - TUD_STAGE + 1 : 0;
+        for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(kc - TUD_STAGE - t > 0 ? kc - TUD_STAGE - t : 0) * a.ld];
+      }
+      const int k_lo = kc - CHUNK + 1 > 0 ? kc - CHUNK + 1 : 0;
+    float od_next = COL ? s_stage[kc][threadIdx.x] : s_stage[0][threadIdx.x];
     for (int k = kc; k >= k_lo; --k) {
-      const float od = s_stage[kc - k][threadIdx.x];
+      const float od = od_next;  // read one layer ahead: the LDS latency hides behind the layer's arithmetic
+      if (k > k_lo) od_next = COL ? s_stage[k - 1][threadIdx.x] : s_stage[kc - k + 1][threadIdx.x];
       const bool streams = k <= k_start;                    // wave-uniform (k_start < nd)
-      const bool up = a0 == 0 && up_live && k < cnt0;       // wave-uniform
-      if (a0 == 0 && ((a.mask[0][k >> 5] >> (k & 31)) & 1u)) s0 += od;
+      const bool up = !(TUD_ABLATE & 4) && a0 == 0 && up_live && k < cnt0;       // wave-uniform
+      if (a0 == 0 && mask0_bit(k)) s0 += od;
       if (!streams && !up) continue;
-      const float B = planck_f32(c1x3, x, a.c2l2e_over_T[k]);
+#if TUD_ABLATE & 2
+      const float B = (float)c1x3 * (1e-3f + od);
+#else
+      const float B = planck_f32(c1x3, x, c2l2e_of(k));
+#endif
       if (up) {
         const float y = od * c0;
         const float e = (y > -TUD_THIN_Y) ? em_thin(y) : 1.0f - __builtin_amdgcn_exp2f(y);
@@ -355,6 +428,10 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       } else if (__ballot(thin) == ~0ull) {
+#if TUD_ABLATE & 1
+        L[0] += B * od;
+        continue;
+#endif
         // 1 - 2^(OD c) as a polynomial in the stream's c with per-lane coefficients A_k = -q_k OD^k (5 multiplies per
         // layer, shared by all streams): 5 VALU per stream instead of forming y and running em_thin (6)
         const float o2 = od * od;
@@ -481,6 +558,219 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Downwelling without streams. Unrolled, stream q's recurrence (:368-372) is
+//   L_q = sum_k B_k (1 - t_kq) prod_{j<k} t_jq = sum_k B_k [ exp(-S_k sec_q) - exp(-S_{k+1} sec_q) ],
+// S_k = the optical depth between the surface and the bottom of layer k, so the weighted sum over the streams (:387-388) is
+//   sum_q w_q L_q = sum_k B_k [ G(S_k) - G(S_{k+1}) ],     G(S) = sum_q w_q exp(-S / cos(theta_q)),
+// the reference's own quadrature regrouped: ONE function of one variable, fixed by N_angle, evaluated at n_layers + 1
+// depths per wavenumber instead of (N_angle - 1) x n_layers stream updates. G is a sum of 29 decaying exponentials with rates
+// 1 .. 19; the host tabulates it once per N_angle as piecewise degree-6 polynomials (fp64 Chebyshev interpolants, 225
+// intervals: 16 per binade of S + 2^-6 below S = 16, width 1/2 above, nothing beyond 48 where G < 1e-20 G(0)) to 4e-14 of
+// G(0), and the kernel evaluates it in fp64, so the differences G(S_k) - G(S_{k+1}) keep their relative accuracy down to
+// layers of OD ~ 1e-9 with no thin / thick / mixed case distinction at all (the stream kernel needed three forms of
+// 1 - t for that). Cost per wavenumber and layer: one fp64 Horner of degree 6 + an index + 4 LDS reads instead of 29 x 6
+// fp32 operations. The per-stream radiances themselves (opts['save']) still come from the stream kernel.
+#define TUDG_M 4                     // 2^M intervals per binade of (S + TUDG_OFF) below TUDG_SWITCH
+#define TUDG_OFF 0.015625f           // 2^-6
+#define TUDG_SWITCH 16.0f
+#define TUDG_SMAX 48.0
+#define TUDG_DEG 6
+#define TUDG_BASE (0x3C800000 >> (23 - TUDG_M))   // bits of 2^-6, shifted
+#define TUDG_NLOG ((0x41800000 >> (23 - TUDG_M)) - TUDG_BASE + 1)  // log-spaced intervals: bits of 16 -> the last one
+#define TUDG_NINT (TUDG_NLOG + (int)((TUDG_SMAX - 16.0) * 2.0))
+
+__device__ __forceinline__ int tudg_index(float sf) {
+  const int il = (__float_as_int(sf + TUDG_OFF) >> (23 - TUDG_M)) - TUDG_BASE;
+  const int iu = TUDG_NLOG + (int)((sf - TUDG_SWITCH) * 2.0f);
+  int idx = sf < TUDG_SWITCH ? il : iu;
+  idx = idx < 0 ? 0 : idx;
+  return idx < TUDG_NINT - 1 ? idx : TUDG_NINT - 1;
+}
+__device__ __forceinline__ double tudg_eval(const double* __restrict__ s_g, double S) {
+  const double Sc = fmin(S, TUDG_SMAX);  // (a NaN depth is flagged by the caller)
+  const int idx = tudg_index((float)Sc);
+  const double2* __restrict__ p = reinterpret_cast<const double2*>(s_g + idx * 8);
+  const double2 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];  // mid a0 | a1 a2 | a3 a4 | a5 a6
+  const double u = Sc - q0.x;
+  double r = q3.y;
+  r = fma(r, u, q3.x); r = fma(r, u, q2.y); r = fma(r, u, q2.x);
+  r = fma(r, u, q1.y); r = fma(r, u, q1.x); r = fma(r, u, q0.y);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void tud_g_kernel(TudArgs a) {
+  __shared__ double s_g[TUDG_NINT * 8];
+  __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots
+  for (int t = threadIdx.x; t < TUDG_NINT * 4; t += 256) reinterpret_cast<double2*>(s_g)[t] = reinterpret_cast<const double2*>(a.gtab)[t];
+  const long long i_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < a.g.n;
+  const long long i = live ? i_raw : a.g.n - 1;  // dead lanes shadow the last point: ballots stay wave-wide
+  const int nL = a.n_layers;
+  const float* __restrict__ od_col = a.OD + i;
+  float nxt[TUD_STAGE];
+#pragma unroll
+  for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(t < nL ? t : nL - 1) * a.ld];
+  const double x = grid_x(a.g, a.g.offset + i);
+  const double x100 = x * 100.0;
+  const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
+  // per-layer constants by v_readlane, the first altitude's mask in scalar registers (as in tud_kernel)
+  const int lane_id = threadIdx.x & 63;
+  const double ct_a = a.c2l2e_over_T[lane_id < nL ? lane_id : 0];
+  const double ct_b = a.c2l2e_over_T[lane_id + 64 < nL ? lane_id + 64 : 0];
+  auto c2l2e_of = [&](int k) -> double {  // k is wave-uniform
+    const double v = k < 64 ? ct_a : ct_b;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), k & 63);
+    return __hiloint2double(hi, lo);
+  };
+  const unsigned mk0 = a.mask[0][0], mk1 = a.mask[0][1], mk2 = a.mask[0][2], mk3 = a.mask[0][3];
+  auto mask0_bit = [&](int k) -> bool {
+    const unsigned w = k < 32 ? mk0 : k < 64 ? mk1 : k < 96 ? mk2 : mk3;
+    return (w >> (k & 31)) & 1u;
+  };
+  __syncthreads();  // the table is in LDS
+
+  // ---- every further (altitude, slant factor) pair: transmittance + upwelling bottom-up (:346-356) ----------
+  for (int p = 1; p < a.n_alt * a.n_mu; ++p) {
+    const int ia = p / a.n_mu, im = p - ia * a.n_mu;
+    const int cnt = a.count[ia];
+    const float c = a.mu_c[im];
+    float s = 0.f, Lu = 0.f;
+    for (int k = 0; k < nL; ++k) {
+      const float od = od_col[(size_t)k * a.ld];
+      if ((a.mask[ia][k >> 5] >> (k & 31)) & 1u) s += od;
+      if (k < cnt) {
+        const float B = planck_f32(c1x3, x, c2l2e_of(k));
+        const float y = od * c;
+        Lu = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - Lu, Lu) : fmaf(__builtin_amdgcn_exp2f(y), Lu - B, B);
+      }
+    }
+    if (live) {
+      const size_t o = (size_t)p * (size_t)a.ld_out + (size_t)i;
+      a.tau[o] = a.return_od ? s * a.mu[im] : __builtin_amdgcn_exp2f(s * c);
+      a.Lu[o] = Lu;
+    }
+  }
+
+  // ---- the first pair's transmittance and upwelling, and the downwelling, in one bottom-up pass -------------------------
+  const int nd = a.n_down, cnt0 = a.count[0];
+  const float c0 = a.mu_c[0];
+  float s0 = 0.f, Lu0 = 0.f, acc = 0.f;
+  double S = 0.0, g_prev = tudg_eval(s_g, 0.0);  // (not a.g0: the table's own value, so that an empty column gives exactly 0)
+  // Downwelling at the surface is blind to everything above the depth where G has dropped to 2^-27 of G(0) times the
+  // column's Planck dynamic range at this wavenumber (what is dropped is at most that transmission times the largest
+  // Planck radiance, what is kept is of the order of the smallest): once every lane is there the wave stops evaluating G.
+  double g_floor;
+  {
+    const float b_hot = planck_f32(c1x3, x, a.c2l2e_over_Tmax), b_cold = planck_f32(c1x3, x, a.c2l2e_over_Tmin);
+    const float r = __builtin_amdgcn_logf(b_hot / b_cold);  // log2
+    const float y_opq = (b_cold > 0.f && r == r && r < 1e30f) ? TUD_OPAQUE_Y + 1.0f + fmaxf(r, 0.f) : 3.0e38f;
+    g_floor = a.g0 * (double)__builtin_amdgcn_exp2f(-fminf(y_opq, 120.0f));
+  }
+  bool down_live = nd > 0;  // wave-uniform
+  for (int kc = 0; kc < nL; kc += TUD_STAGE) {
+#pragma unroll
+    for (int t = 0; t < TUD_STAGE; ++t) s_stage[t][threadIdx.x] = nxt[t];
+#pragma unroll
+    for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(kc + TUD_STAGE + t < nL ? kc + TUD_STAGE + t : nL - 1) * a.ld];
+    const int k_hi = kc + TUD_STAGE < nL ? kc + TUD_STAGE : nL;
+    for (int k = kc; k < k_hi; ++k) {
+      const float od = s_stage[k - kc][threadIdx.x];
+      if (mask0_bit(k)) s0 += od;
+      const bool up = k < cnt0, dn = down_live && k < nd;  // wave-uniform
+      if (!up && !dn) continue;
+      const float B = planck_f32(c1x3, x, c2l2e_of(k));
+      if (up) {
+        const float y = od * c0;
+        Lu0 = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - Lu0, Lu0) : fmaf(__builtin_amdgcn_exp2f(y), Lu0 - B, B);
+      }
+      if (dn) {
+        S += (double)od;
+        const double g = tudg_eval(s_g, S);
+        acc = fmaf(B, (float)(g_prev - g), acc);
+        g_prev = g;
+        if (__ballot(g > g_floor) == 0ull) down_live = false;
+      }
+    }
+  }
+  if (live) {
+    a.tau[i] = a.return_od ? s0 * a.mu[0] : __builtin_amdgcn_exp2f(s0 * c0);
+    a.Lu[i] = Lu0;
+    a.Ld[i] = (S != S) ? __builtin_nanf("") : acc * a.inv_wsum;  // a NaN optical depth poisons the sum, as in the reference
+  }
+}
+
+// Host side of G: piecewise Chebyshev interpolants of degree TUDG_DEG in fp64, stored as monomials in (S - mid).
+#include <map>
+#include <mutex>
+#include <vector>
+struct GTab { double* dev; double g0; };
+static int tudg_table(int n_angle, GTab* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, GTab> cache;  // (device, n_angle)
+  int dev = 0;
+  RTX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find({dev, n_angle});
+  if (it != cache.end()) { *out = it->second; return 0; }
+  std::vector<double> w, sec;
+  const double dth = (M_PI / 2.0) / (double)n_angle;
+  double g0 = 0.0;
+  for (int ii = 1; ii < n_angle; ++ii) {  // theta = 0 has weight exactly 0
+    const double th = (double)ii * dth;
+    w.push_back(cos(th) * sin(th));
+    sec.push_back(1.0 / cos(th));
+    g0 += w.back();
+  }
+  auto G = [&](double S) { double r = 0.0; for (size_t q = 0; q < w.size(); ++q) r += w[q] * exp(-S * sec[q]); return r; };
+  constexpr int N = TUDG_DEG + 1;
+  std::vector<double> tab((size_t)TUDG_NINT * 8, 0.0);
+  for (int idx = 0; idx < TUDG_NINT; ++idx) {
+    double lo, hi;
+    if (idx < TUDG_NLOG) {
+      union { int i; float f; } a0, a1;
+      a0.i = (TUDG_BASE + idx) << (23 - TUDG_M);
+      a1.i = (TUDG_BASE + idx + 1) << (23 - TUDG_M);
+      lo = (double)a0.f - (double)TUDG_OFF;
+      hi = (double)a1.f - (double)TUDG_OFF;
+      if (lo < 0.0) lo = 0.0;
+      if (hi > (double)TUDG_SWITCH) hi = (double)TUDG_SWITCH;
+    } else {
+      lo = (double)TUDG_SWITCH + 0.5 * (idx - TUDG_NLOG);
+      hi = lo + 0.5;
+    }
+    const double mid = 0.5 * (lo + hi), hw = 0.5 * (hi - lo) * 1.002;  // a little wider than the bucket: (float)S rounds at the edges
+    double y[N], c[N];
+    for (int k = 0; k < N; ++k) y[k] = G(mid + hw * cos(M_PI * (k + 0.5) / N));
+    for (int j = 0; j < N; ++j) {
+      double sacc = 0.0;
+      for (int k = 0; k < N; ++k) sacc += y[k] * cos(M_PI * j * (k + 0.5) / N);
+      c[j] = sacc * (j == 0 ? 1.0 : 2.0) / N;
+    }
+    // Chebyshev -> monomials in t = u / hw:  T0 = 1, T1 = t, T_{n+1} = 2 t T_n - T_{n-1}
+    double mono[N] = {0}, Tm[N] = {0}, Tc[N] = {0}, Tn[N];
+    Tm[0] = 1.0;  // T0
+    Tc[1] = 1.0;  // T1
+    mono[0] += c[0];
+    if (N > 1) mono[1] += c[1];
+    for (int n = 2; n < N; ++n) {
+      for (int d = 0; d < N; ++d) Tn[d] = (d > 0 ? 2.0 * Tc[d - 1] : 0.0) - Tm[d];
+      for (int d = 0; d < N; ++d) { mono[d] += c[n] * Tn[d]; Tm[d] = Tc[d]; Tc[d] = Tn[d]; }
+    }
+    double* row = &tab[(size_t)idx * 8];
+    row[0] = mid;
+    double sc = 1.0;
+    for (int d = 0; d < N; ++d) { row[1 + d] = mono[d] * sc; sc /= hw; }
+  }
+  GTab t;
+  t.g0 = g0;
+  RTX_HIP(hipMalloc(&t.dev, tab.size() * sizeof(double)));
+  RTX_HIP(hipMemcpy(t.dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  cache[{dev, n_angle}] = t;
+  *out = t;
+  return 0;
+}
+
 template <int NA>
 static int launch_tud(TudArgs& a, int na, hipStream_t st) {
   const int na_pad = na == 0 ? NA : ((na + NA - 1) / NA) * NA;  // at least one block: it carries tau and L-up
@@ -492,7 +782,10 @@ static int launch_tud(TudArgs& a, int na, hipStream_t st) {
   a.ang_cmin = cmin; a.ang_cmax = cmax;
   a.n_ang = na_pad;
   const long long blocks = (a.g.n + 255) / 256;
-  hipLaunchKernelGGL(tud_kernel<NA>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  if (a.n_layers <= TUD_COL_LAYERS)
+    hipLaunchKernelGGL((tud_kernel<NA, true>), dim3((unsigned)blocks), dim3(256), (size_t)a.n_layers * 256 * sizeof(float), st, a);
+  else
+    hipLaunchKernelGGL((tud_kernel<NA, false>), dim3((unsigned)blocks), dim3(256), (size_t)TUD_STAGE * 256 * sizeof(float), st, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }
@@ -550,6 +843,19 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
   // streams per register block: the smallest instantiated width that holds them all (N_angle = 30 -> 29
   // evaluated -> 29 registers, no padding); more than 32 streams run in blocks of 32
   hipStream_t st = (hipStream_t)stream;
+  // default: the angle-summed form; the stream kernel when the caller wants the per-stream radiances
+  // (RADTXFR_TUD_KERNEL=streams forces it, for cross-checks and timing)
+  static int force_streams = -1;
+  if (force_streams < 0) { const char* e = getenv("RADTXFR_TUD_KERNEL"); force_streams = (e && !strcmp(e, "streams")) ? 1 : 0; }
+  if (!Ld_angles && !force_streams) {
+    GTab gt;
+    if (tudg_table(n_angle, &gt)) return 1;
+    a.gtab = gt.dev; a.g_nint = TUDG_NINT; a.g0 = gt.g0;
+    const long long blocks = (a.g.n + 255) / 256;
+    hipLaunchKernelGGL(tud_g_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    RTX_LAUNCH_CHECK();
+    return 0;
+  }
   if (na <= 4) return launch_tud<4>(a, na, st);
   if (na <= 8) return launch_tud<8>(a, na, st);
   if (na <= 16) return launch_tud<16>(a, na, st);
