@@ -716,6 +716,61 @@ def test_tud_random_configurations_vs_oracle():
             assert np.isnan(dr).all() and bool(torch.isnan(Ld).all()), tag
         else:
             assert rel_err(Ld.double().cpu().numpy(), dr) <= TOL_L, tag
+        # the downwelling above came from the angle-summed form (tud_g_kernel); asking for the per-stream radiances runs
+        # the stream kernel (column resident in LDS up to 36 layers, chunked beyond): same tau / L-up / L-down, and the
+        # streams themselves against the reference's own recurrence per angle
+        t2, u2, Ld2, _, Ld_ang = engine.tud(torch.as_tensor(OD, device="cuda"), grid, T, Z, Altitudes=alts, theta_r=theta,
+                                            N_angle=nA, returnOD=ret_od, per_angle=True)
+        if ret_od:
+            assert rel_err(t2.double().cpu().numpy(), tau.double().cpu().numpy()) <= 2e-6, tag
+        else:  # (the two kernels add the column's OD in opposite orders)
+            assert float((t2 - tau).abs().max()) <= TOL_TAU, tag
+        assert rel_err(u2.double().cpu().numpy(), Lu.double().cpu().numpy()) <= 2e-6, tag
+        if nA > 1:
+            assert rel_err(Ld2.double().cpu().numpy(), dr) <= TOL_L, tag
+            assert rel_err(Ld2.double().cpu().numpy(), Ld.double().cpu().numpy()) <= 3e-6, tag
+        nd = int((Z <= np.asarray(alts).ravel()[-1]).sum())
+        Bk = ref.planckian(X, T)                      # (n, nL)
+        for q in rng.choice(nA, size=min(nA, 3), replace=False):
+            sec = 1.0 / np.cos(q * (np.pi / 2) / nA)
+            Lq = np.zeros(n)
+            for j in range(nd - 1, -1, -1):
+                t = np.exp(-OD[j].astype(np.float64) * sec)
+                Lq = t * Lq + (1.0 - t) * Bk[:, j]
+            assert rel_err(Ld_ang[q].double().cpu().numpy(), Lq) <= TOL_L, (tag, int(q))
+
+
+def test_tud_downwelling_table_extremes():
+    """The angle-summed downwelling (tud_g_kernel) at the ends of its table: columns from 1e-9 to 1e4 total optical
+    depth (thin layers over thick ones and the reverse), an all-zero column (exactly 0), a NaN depth (NaN like the
+    reference's recurrence), slightly negative depths (rounding noise of a caller's own OD), N_angle from 2 to 96."""
+    import torch
+    from radtxfr_amd import engine
+
+    rng = np.random.default_rng(20261012)
+    nL, n = 32, 1024
+    Z = np.linspace(0.0, 9.5, nL)
+    T = np.linspace(288.0, 226.0, nL)
+    grid = engine.Grid(800.0, 801.0, n)
+    X = grid.axis()
+    for nA in (2, 3, 30, 96):
+        OD = np.empty((nL, n), dtype=np.float32)
+        tot = 10.0 ** np.linspace(-9.0, 4.0, n)                     # total depth of column i
+        prof = rng.dirichlet(np.full(nL, 0.3), size=n).T            # how it is spread over the layers: very uneven
+        OD[:] = (tot[None, :] * prof).astype(np.float32)
+        OD[:, 5] = 0.0
+        OD[:, 7] = -1e-7 * rng.uniform(0, 1, nL)
+        tau, Lu, Ld, _ = engine.tud(torch.as_tensor(OD, device="cuda"), grid, T, Z, N_angle=nA)
+        tr, ur, dr = ref.tud_from_od(X, OD.astype(np.float64).T, T, Z, N_angle=nA)
+        Ld_h = Ld.double().cpu().numpy()
+        assert Ld_h[5] == 0.0
+        # relative to each column's own radiance (no floor: the thin columns carry 1e-9 of the thick ones' radiance)
+        ok = np.abs(dr) > 0
+        assert np.max(np.abs(Ld_h[ok] - dr[ok]) / np.abs(dr[ok])) <= TOL_L, nA
+        assert rel_err(Lu.double().cpu().numpy().ravel(), ur) <= TOL_L
+        OD[3, 11] = np.nan
+        tau, Lu, Ld, _ = engine.tud(torch.as_tensor(OD, device="cuda"), grid, T, Z, N_angle=nA)
+        assert bool(torch.isnan(Ld[11])) and not bool(torch.isnan(Ld[12]))
 
 
 # --------------------------------------------------------------------- line-sum: randomised grids and states

@@ -9,6 +9,6 @@ for f in glob.glob(d + '/**/*_counter_collection.csv', recursive=True):
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         calls[(k, r['Counter_Name'])] += 1
     for k, v in agg.items():
-        if any(s in k for s in ('voigt', 'tud_kernel', 'prep', 'ils', 'radiance')):
+        if any(s in k for s in ('voigt', 'tud_', 'prep', 'ils', 'radiance')):
             n = max(calls[(k, c)] for c in v)
             print(k, 'launches', n, {a: '%.4g' % (b / n) for a, b in sorted(v.items())})
