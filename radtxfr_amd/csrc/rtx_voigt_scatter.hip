@@ -377,14 +377,17 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #ifndef RTX_SC_WAVES
 #define RTX_SC_WAVES 6
 #endif
-#ifndef SC_ENT_CAP
-#define SC_ENT_CAP 16  // point-by-point entries per wave (64 B each); 23 is the most that keeps 6 workgroups per CU in LDS
+#ifndef SC_NW
+#define SC_NW 2  // waves per workgroup of the nodal kernel (each takes every SC_NW-th candidate and owns a copy of the tile). 4 -> 2: the row-level groups of 8 member lines fill better when a wave sees twice the candidates (2.10 -> 2.02 ms); 1: the same as 2
 #endif
-__global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a) {
+#ifndef SC_ENT_CAP
+#define SC_ENT_CAP 32  // point-by-point entries per wave (64 B each). With two waves per workgroup: 16 -> 2.02 ms, 24 -> 1.99, 32 -> 1.96, 48 -> 2.03
+#endif
+__global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
-  __shared__ float s_acc[4][TILE];              // one private tile per wave (near rows)
-  __shared__ float4 s_ent[4][SC_ENT_CAP][4];
+  __shared__ float s_acc[SC_NW][TILE];              // one private tile per wave (near rows)
+  __shared__ float4 s_ent[SC_NW][SC_ENT_CAP][4];
   __shared__ float s_nodsum[RTX_SC_ROWS][CHEB_N];
   // after the last drain the entry lists are dead: wave w keeps its row-level sums [ROWS][8] in its list
   static_assert(RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "row sums fit in one wave's entry list");
@@ -473,9 +476,9 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
     n_ent = 0;
   };
 
-  // 256 candidates per round: wave w, lane i takes candidate rng.x + w + 4 i (+ 256 per round)
-  for (int base = rng.x + wave; base < rng.y; base += 256) {
-    const int slot = base + 4 * lane;
+  // 64 SC_NW candidates per round: wave w, lane i takes candidate rng.x + w + SC_NW i (+ 64 SC_NW per round)
+  for (int base = rng.x + wave; base < rng.y; base += 64 * SC_NW) {
+    const int slot = base + SC_NW * lane;
     const bool valid = slot < rng.y;
     const float4* __restrict__ pr = reinterpret_cast<const float4*>(rec + (valid ? slot : rng.y - 1));
     const float4 f0 = pr[0];  // a c b1 b0
@@ -553,15 +556,25 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
         } else {
           int mf = __builtin_amdgcn_ds_bpermute(sl << 2, (int)m_far);
           mf = e < nR ? mf : 0;
-#pragma unroll
-          for (int r = 0; r < ROWS; ++r) {
-            const float x = fmaf((float)r, dx, x0);
-            const float xx = x * x;
-            float num = fmaf(xx, qAy, qAy0);
-            const float rden = __builtin_amdgcn_rcpf(fmaf(xx + qb1, xx, qb0));
-            num = __int_as_float(__float_as_int(num) & __builtin_amdgcn_sbfe(mf, r, 1));
-            nod[r] = fmaf(num, rden, nod[r]);
+          // row r counts for this member iff bit r of its mask is set: v_bfe_i32 (bit -> 0 / -1) + v_and_b32 on the numerator,
+          // two full-rate instructions (written as `x & sbfe(mf, r, 1)` the compiler turns it into and + compare + select,
+          // and a select reads its mask from scalar registers: half rate, tools/ubench_enc.hip)
+#define SC_PART_ROW(r_)                                                                  \
+          if (r_ < ROWS) {                                                                 \
+            const float x = fmaf((float)(r_), dx, x0);                                     \
+            const float xx = x * x;                                                        \
+            float num = fmaf(xx, qAy, qAy0);                                               \
+            const float rden = __builtin_amdgcn_rcpf(fmaf(xx + qb1, xx, qb0));             \
+            int mb;                                                                        \
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mb) : "v"(mf), "n"(r_));                  \
+            num = __int_as_float(__float_as_int(num) & mb);                                \
+            nod[r_ < ROWS ? r_ : 0] = fmaf(num, rden, nod[r_ < ROWS ? r_ : 0]);            \
           }
+          SC_PART_ROW(0) SC_PART_ROW(1) SC_PART_ROW(2) SC_PART_ROW(3) SC_PART_ROW(4) SC_PART_ROW(5) SC_PART_ROW(6) SC_PART_ROW(7)
+          SC_PART_ROW(8) SC_PART_ROW(9) SC_PART_ROW(10) SC_PART_ROW(11) SC_PART_ROW(12) SC_PART_ROW(13) SC_PART_ROW(14) SC_PART_ROW(15)
+          SC_PART_ROW(16) SC_PART_ROW(17) SC_PART_ROW(18) SC_PART_ROW(19) SC_PART_ROW(20) SC_PART_ROW(21) SC_PART_ROW(22) SC_PART_ROW(23)
+          SC_PART_ROW(24) SC_PART_ROW(25) SC_PART_ROW(26) SC_PART_ROW(27) SC_PART_ROW(28) SC_PART_ROW(29) SC_PART_ROW(30)
+#undef SC_PART_ROW
         }
       }
     }
@@ -581,11 +594,13 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
   STAMP(2);
   __syncthreads();
   STAMP(6);  // barrier
-  // stage 1: thread (r, jj) adds the four waves' row-level sums in a fixed order
-  if (threadIdx.x < ROWS * CHEB_N) {
-    const int o = threadIdx.x;  // = r * CHEB_N + jj
-    s_nodsum[o >> 3][o & 7] = (reinterpret_cast<const float*>(&s_ent[0][0][0])[o] + reinterpret_cast<const float*>(&s_ent[1][0][0])[o]) +
-                              (reinterpret_cast<const float*>(&s_ent[2][0][0])[o] + reinterpret_cast<const float*>(&s_ent[3][0][0])[o]);
+  // stage 1: thread (r, jj) adds the waves' row-level sums in a fixed order
+  static_assert(SC_NW == 1 || SC_NW == 2 || SC_NW == 4, "one, two or four waves per workgroup");
+  for (int o = threadIdx.x; o < ROWS * CHEB_N; o += 64 * SC_NW) {  // o = r * CHEB_N + jj
+    float v = reinterpret_cast<const float*>(&s_ent[0][0][0])[o];
+    if (SC_NW >= 2) v += reinterpret_cast<const float*>(&s_ent[1][0][0])[o];
+    if (SC_NW == 4) v += reinterpret_cast<const float*>(&s_ent[2][0][0])[o] + reinterpret_cast<const float*>(&s_ent[3][0][0])[o];
+    s_nodsum[o >> 3][o & 7] = v;
   }
   __syncthreads();
   // stage 2: row nodes -> grid points, plus the four point-by-point copies; coalesced stores
@@ -594,13 +609,16 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
 #pragma unroll
     for (int jj = 0; jj < CHEB_N; ++jj) wl[jj] = CHEB_W[lane][jj];
 #pragma unroll 4
-    for (int r = wave; r < ROWS; r += 4) {
+    for (int r = wave; r < ROWS; r += SC_NW) {
       const int t = r * 64 + lane;
       const long long i = (long long)ia + t;
       float f = 0.f;
 #pragma unroll
       for (int jj = 0; jj < CHEB_N; ++jj) f = fmaf(wl[jj], s_nodsum[r][jj], f);
-      const float v = ((s_acc[0][t] + s_acc[1][t]) + (s_acc[2][t] + s_acc[3][t])) + f;
+      float pp = s_acc[0][t];
+      if (SC_NW >= 2) pp += s_acc[1][t];
+      if (SC_NW == 4) pp += s_acc[2][t] + s_acc[3][t];
+      const float v = pp + f;
       if (i < (long long)ib) {
         const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
         if (a.out32) a.out32[o] = v;
@@ -611,7 +629,7 @@ __global__ __launch_bounds__(256, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a
   if (RTX_SC_STAMP) {
     t_ph[7] = (long long)clock64() - t_begin;  // lifetime (includes the final stages, which have no bucket of their own)
     if (lane == 0) {
-      unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * SC_NSTAMP;
+      unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * SC_NW + wave) * SC_NSTAMP;
       for (int i = 0; i < SC_NSTAMP; ++i) o[i] = (unsigned long long)t_ph[i];
     }
   }
@@ -637,7 +655,7 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
 #if RTX_SC_STAMP
   static unsigned long long* d_stamp = nullptr;
   static size_t stamp_cap = 0;
-  const size_t n_stamp = (size_t)8 * a.tiles_per_xcd * n_layers * 4 * SC_NSTAMP;
+  const size_t n_stamp = (size_t)8 * a.tiles_per_xcd * n_layers * SC_NW * SC_NSTAMP;
   if (stamp_cap < n_stamp) {
     if (d_stamp) RTX_HIP(hipFree(d_stamp));
     RTX_HIP(hipMalloc(&d_stamp, n_stamp * sizeof(unsigned long long)));
@@ -649,7 +667,7 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   // RADTXFR_DEBUG_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, to time the kernel at reduced occupancy
   static int lds_pad = -1;
   if (lds_pad < 0) { const char* e = getenv("RADTXFR_DEBUG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
-  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), (size_t)lds_pad, st, a);
+  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(64 * SC_NW), (size_t)lds_pad, st, a);
   else hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
 #if RTX_SC_STAMP
@@ -663,7 +681,7 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
     }
     double h[SC_NSTAMP] = {0};
     for (size_t i = 0; i < n_stamp; ++i) h[i % SC_NSTAMP] += (double)hbuf[i];
-    const double w = 4.0 * 8 * a.tiles_per_xcd * n_layers;
+    const double w = (double)SC_NW * 8 * a.tiles_per_xcd * n_layers;
     fprintf(stderr, "[stamp] per wave (s_memtime ticks): load+geom %.0f emit %.0f rowlevel %.0f entry %.0f pp %.0f band %.0f barrier %.0f life %.0f\n",
             h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
   }
