@@ -1,6 +1,6 @@
 // Voigt line-sum, "scatter into per-wave LDS tiles" formulations: the default nodal kernel and the point-by-point
-// scatter kernel it grew out of (rtx_voigt.hip holds the dispatcher and the earlier register-accumulator gather
-// kernel; all three share the record layout and the Weideman code).
+// scatter kernel it grew out of, kept as its cross-check and as the fp64 pass for Doppler-dominated lines (rtx_voigt.hip
+// holds the dispatcher; both kernels share the record layout and the Weideman code of rtx_voigt_math.h).
 //
 // A workgroup owns a tile of SC_TILE consecutive grid points of one layer; EACH LINE IS TAKEN BY EXACTLY ONE
 // WAVE, which accumulates the line into ITS OWN copy of the tile in LDS (plain ds_read/add/ds_write: no other
@@ -25,9 +25,9 @@
 //                                by vector loads, no scalar work per line: ~1.6 VALU slots per (line, row)
 //                                against ~11 for the point-by-point form, and C3's windows are ~80 rows wide.
 //
-// Summation order: a point's value is a fixed function of the tiling; a different tiling (another wavenumber
-// shard) regroups the fp32 sums and may differ in the last bits (the gather kernel is bit-identical across
-// shards; tests allow 1e-6 here).
+// Summation order: a point's value is a fixed function of the tiling; a different tiling (a wavenumber shard that
+// does not start on a tile boundary) regroups the fp32 sums and may differ in the last bits (tests allow 3e-6; shards
+// aligned to the tile, as dist.py cuts them, are bit-identical to the single-rank result).
 #include "rtx_common.h"
 
 #include "rtx_voigt_math.h"
@@ -374,6 +374,10 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 // lines two segment lengths away evaluated at 8 nodes per 16-, 8- or 4-row segment, a third of all (line, tile) pairs, 1.5x
 // fewer node evaluations, same 2.3e-7 accuracy -- with its three extra compaction passes (2.44 vs 2.24: a pass's fixed cost,
 // one ds_permute + nine ds_bpermute per group of 8 lines, outweighs the evaluations it saves).
+// Later in round 2: two waves per workgroup instead of four, 32-entry lists (2.10 -> 1.93: a wave that sees twice the candidates
+// fills its groups of 8 members better; one wave per workgroup: the same), the Weideman halves by the real two-term recurrence
+// (2.25 -> 2.17). Measured slower: one compaction for full and partial members together with only the last group mixed (15
+// spilled registers, 2.08 vs 1.93), the next entry read ahead in the final drain (2.00 vs 1.93).
 #ifndef RTX_SC_WAVES
 #define RTX_SC_WAVES 6
 #endif
