@@ -253,11 +253,6 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     const double nu = a.nu[l];
     const int sp = a.species[l];
     const double w = ew[(size_t)sp * a.n_layers + k];
-    // S(T): EnvironmentDependency_Intensity, misc/hapi.py:10169-10175 (SigmaTref/SigmaT = qratio)
-    const double el = a.elower[l];
-    const double ch = exp(-H_C2 * el / T) * (1.0 - exp(-H_C2 * nu / T));
-    const double zn = exp(-H_C2 * el / H_TREF) * (1.0 - exp(-H_C2 * nu / H_TREF));
-    const double S = a.sw[l] * eq[(size_t)sp * a.n_layers + k] * ch / zn;
     // GammaD, misc/hapi.py:11085-11087
     const double m = em[sp] * H_CMASSMOL * 1000.0;
     double GammaD = sqrt(2.0 * H_CBOLTS * T * log(2.0) / m / (H_CC * H_CC)) * nu;
@@ -290,10 +285,47 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     long long glo = grid_bisect_right(g, nu - W);
     long long ghi = grid_bisect_right(g, nu + W);
     int lo = clamp_local(glo, g), hi = clamp_local(ghi, g);
-    const bool dropped = !(w != 0.0) || (S < a.thresh) || !(GammaD > 0.0) || (a.profile == RTX_PROFILE_LORENTZ && !(Gamma0 > 0.0));
+    const double sg0 = nu + Shift0;
+    const long long M = 1000000000LL;
+    if (k == 0) {
+      long long gic = llrint((nu - g.xmin) / g.step);
+      if (gic < -M) gic = -M;
+      if (gic > M) gic = M;
+      a.ic[l] = sat_local(gic - g.offset, g.n);
+    }
+    // A wavenumber SHARD (one rank of N) is reached by ~1/N of the table, but every rank runs this prologue over all of it
+    // (the candidate ranges, hence the order of the fp32 sums, must not depend on where the shard is cut: maxhw below is a
+    // maximum over the whole table). A line whose window ends a grid step or more outside the shard contributes nothing
+    // here and its record is read at most as a rejected tile candidate, so the
+    // rest of the work (S(T): four fp64 exponentials, the profile constants, 80 bytes of records) is skipped for it. Not
+    // with an intensity threshold (whether the line counts for maxhw then depends on S) and not for the SD-Voigt records.
+    const bool pre_dropped = !(w != 0.0) || !(GammaD > 0.0) || (a.profile == RTX_PROFILE_LORENTZ && !(Gamma0 > 0.0));
+    const bool outside = nu + W < grid_x(g, g.offset) - g.step || nu - W > grid_x(g, g.offset + g.n - 1) + g.step;
+    const bool skip = outside && !(a.thresh > 0.0) && a.profile != RTX_PROFILE_SDVOIGT;
+    if (skip) {
+      long long gi0 = llrint((sg0 - g.xmin) / g.step);
+      if (gi0 < -M) gi0 = -M;
+      if (gi0 > M) gi0 = M;
+      const size_t o = (size_t)k * (size_t)a.n_lines + (size_t)l;
+      // lo = hi = 0 rejects it; the other fields are finite and give a zero contribution with a non-zero denominator (the
+      // line-sum fills the empty slots of a group of 8 from whatever candidate lane is at hand and zeroes the numerator)
+      LineRec r;
+      r.a = 0.f; r.c = 0.f; r.b1 = 0.f; r.b0 = 1.f; r.Ay = 0.f; r.Ay0 = 0.f; r.y = 15.f; r.A = 0.f;
+      r.i0 = sat_local(gi0 - g.offset, g.n); r.lo = 0; r.hi = 0; r.zw = 0;
+      a.rec[o] = r;
+      if (!pre_dropped && ghi > glo) {
+        double hw = ceil(W / g.step) + 2.0;
+        my_hw = hw > 1.0e9 ? 1000000000 : (int)hw;
+      }
+    } else {
+    // S(T): EnvironmentDependency_Intensity, misc/hapi.py:10169-10175 (SigmaTref/SigmaT = qratio)
+    const double el = a.elower[l];
+    const double ch = exp(-H_C2 * el / T) * (1.0 - exp(-H_C2 * nu / T));
+    const double zn = exp(-H_C2 * el / H_TREF) * (1.0 - exp(-H_C2 * nu / H_TREF));
+    const double S = a.sw[l] * eq[(size_t)sp * a.n_layers + k] * ch / zn;
+    const bool dropped = pre_dropped || (S < a.thresh);
     if (dropped || hi <= lo) { lo = 0; hi = 0; }
     // profile parameters: pcqsdhc PART1, misc/hapi.py:9900-9915
-    const double sg0 = nu + Shift0;
     // Lorentz (PROFILE_LORENTZ, misc/hapi.py:10150): with x = (nu - sg0)/Gamma0 the profile is (1/(pi Gamma0)) / (x^2 + 1)
     // = (x^2 K + K) / ((x^2 + 2) x^2 + 1), i.e. the line-sum's far-wing rational with b1 = 2, b0 = 1, Ay = Ay0 = K:
     // the same kernels evaluate it everywhere (no band: y is set to 15), poles at |nu - sg0| = Gamma0 as for Voigt.
@@ -305,7 +337,6 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     const double A = dropped ? 0.0 : (lor ? w * S * cte / M_PI * a.scale : w * S * cte / sqrt(M_PI) * a.scale);
     // nearest grid index to the shifted centre (global), then the residual in fp64
     long long gi0 = llrint((sg0 - g.xmin) / g.step);
-    const long long M = 1000000000LL;
     if (gi0 < -M) gi0 = -M;
     if (gi0 > M) gi0 = M;
     const double frac_x = (grid_x(g, gi0) - sg0) * cte;  // x at gi0, |.| <= a/2 when inside the grid
@@ -345,12 +376,6 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       q.nu = nu; q.cte = cte; q.Gam0 = Gamma0; q.Shift0 = Shift0; q.Gam2 = Gam2; q.WS = dropped ? 0.0 : w * S;
       a.recsd[o] = q;
     }
-    if (k == 0) {
-      long long gic = llrint((nu - g.xmin) / g.step);
-      if (gic < -M) gic = -M;
-      if (gic > M) gic = M;
-      a.ic[l] = sat_local(gic - g.offset, g.n);
-    }
     if (!dropped && ghi > glo) {
       // window half-width in grid points, measured from the unshifted centre, with margin. Taken over every live line
       // whose window meets the FULL axis, not only this shard: the per-tile candidate ranges -- hence the order of the
@@ -358,6 +383,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       double hw = ceil(W / g.step) + 2.0;
       my_hw = hw > 1.0e9 ? 1000000000 : (int)hw;
     }
+    }  // !skip
   }
   // block max -> one atomic per block
   for (int off = 32; off > 0; off >>= 1) my_hw = max(my_hw, __shfl_down(my_hw, off));

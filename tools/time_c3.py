@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--n", type=int, default=5500000)
 ap.add_argument("--layers", type=int, default=32)
+ap.add_argument("--shard", type=str, default="", help="R/N: time rank R's wavenumber shard of N, with the FULL line table")
 ap.add_argument("--mf-scale", type=float, default=1.0, help="scale the mixing ratios (1e-4: an optically thin column, tau ~ 0.5-1 between lines)")
 args = ap.parse_args()
 lib = _lib.load()
@@ -19,6 +20,11 @@ A = synthetic.load_standard_atmosphere()[:args.layers]
 atm = dict(Zs=A[:, 1], Ts=A[:, 5], Ps=A[:, 4], PLs=A[:, 3], MFs_VAL=A[:, 6:8] * 1e6 * args.mf_scale, MFs_ID=np.array([1, 2]))
 lines = engine.LineTable(full)
 grid = engine.Grid(500.0, 6000.0, args.n)
+if args.shard:
+    from radtxfr_amd import dist
+    r, nw = (int(t) for t in args.shard.split("/"))
+    off, cnt, _ = dist.shard_bounds(args.n, nw, r)
+    grid = grid.shard(off, cnt)  # (full line table: what dist.hsi_cube_from_atmosphere hands every rank)
 T, Z = atm["Ts"], atm["Zs"]
 w, p_atm = engine.layer_weights_od(lines.species, T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
 qr, mass = engine.species_factors(lines.species, T)
