@@ -154,7 +154,10 @@ int rtx_bt2l(const double* X, int64_t nx, const double* T, int64_t m, int wavele
  *   outputs: tau[n_alt*n_mu][ld_out], Lu[n_alt*n_mu][ld_out] (index a*n_mu+m), Ld[ld_out];
  *   Ld_angles: NULL, or [n_angle][ld_out] per-stream downwelling radiances (what opts['save']
  *   dumps as Ld, :374-386);
- *   return_od != 0 puts sum(OD*mu) in the tau slot (:349-350). */
+ *   return_od != 0 puts sum(OD*mu) in the tau slot (:349-350).
+ * The weighted stream sum is evaluated as sum_k B_k [G(S_k) - G(S_k+1)], G(S) = sum_q w_q exp(-S/cos
+ * theta_q) tabulated per n_angle in fp64 (the same quadrature, summed over the angles first); with
+ * Ld_angles the streams themselves are run (both against the reference's recurrence to <= 1e-5). */
 int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_layers, const double* T_h,
             int n_alt, const uint8_t* mask_h, int n_mu, const double* mu_h, int n_down,
             int n_angle, int return_od, float* tau, float* Lu, float* Ld, float* Ld_angles,
