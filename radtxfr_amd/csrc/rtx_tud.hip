@@ -214,9 +214,6 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 #ifndef TUD_ABLATE
 #define TUD_ABLATE 0  /* timing experiments: 1 = all-thin layers skip the stream updates, 2 = no Planck evaluation, 4 = no up-path */
 #endif
-#ifndef TUD_CTH_VGPR
-#define TUD_CTH_VGPR 0
-#endif
 #ifndef TUD_ILP
 #define TUD_ILP 8  // streams advanced together, step by step, in the all-thick / all-thin layers
 #endif
@@ -357,9 +354,6 @@ __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
     for (int q = 0; q < NA; ++q) {
       L[q] = 0.f;
       cth[q] = a.ang_c[a0 + q];  // slots past n_ang_real hold the weight-0 nadir stream
-#if TUD_CTH_VGPR
-      asm volatile("" : "+v"(cth[q]));  // keep the stream constants in vector registers (see TUD_CTH_VGPR)
-#endif
     }
     const float c_min = a.ang_cmin, c_max = a.ang_cmax;  // |c| range over the streams (nadir .. most oblique)
     // OD is fetched TUD_STAGE layers at a time: the loads of the next chunk are issued before the current chunk is
