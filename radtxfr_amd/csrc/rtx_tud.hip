@@ -694,6 +694,240 @@ __global__ __launch_bounds__(256) void tud_g_kernel(TudArgs a) {
   }
 }
 
+// PB = (altitude, slant) pairs advanced together in one bottom-up pass: they share the OD loads and the Planck values (the
+// reference's main caller asks for 9 sensor altitudes, Generate_LWIR_TUD.py:81; one pass per pair recomputed B for each).
+// A single pair takes tud_g_kernel above (70 registers, 7 waves per SIMD); several run here in blocks of PB = 8 (109
+// registers), the first block carrying the downwelling.
+#ifndef TUDG_PB
+#define TUDG_PB 3  // 9 pairs, ms: blocks of 2 -> 1.29, 3 -> 1.01, 4 -> 1.15, 8 -> 1.32 (one pass per pair: 1.41)
+#endif
+#ifndef TUDG_PAIR_BALLOT
+#define TUDG_PAIR_BALLOT 0  // 1: one form only where the whole wave agrees (1.48 against 1.15 at blocks of 4: the branches cost more)
+#endif
+template <int PB>
+__global__ __launch_bounds__(256) void tud_g_pairs_kernel(TudArgs a) {
+  __shared__ double s_g[TUDG_NINT * 8];
+  __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots
+  for (int t = threadIdx.x; t < TUDG_NINT * 4; t += 256) reinterpret_cast<double2*>(s_g)[t] = reinterpret_cast<const double2*>(a.gtab)[t];
+  const long long i_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < a.g.n;
+  const long long i = live ? i_raw : a.g.n - 1;  // dead lanes shadow the last point: ballots stay wave-wide
+  const int nL = a.n_layers;
+  const float* __restrict__ od_col = a.OD + i;
+  const double x = grid_x(a.g, a.g.offset + i);
+  const double x100 = x * 100.0;
+  const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
+  // per-layer constants by v_readlane (as in tud_kernel)
+  const int lane_id = threadIdx.x & 63;
+  const double ct_a = a.c2l2e_over_T[lane_id < nL ? lane_id : 0];
+  const double ct_b = a.c2l2e_over_T[lane_id + 64 < nL ? lane_id + 64 : 0];
+  auto c2l2e_of = [&](int k) -> double {  // k is wave-uniform
+    const double v = k < 64 ? ct_a : ct_b;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), k & 63);
+    return __hiloint2double(hi, lo);
+  };
+  __syncthreads();  // the table is in LDS
+
+  const int nd = a.n_down;
+  const int npair = a.n_alt * a.n_mu;
+  float acc = 0.f;
+  double S = 0.0, g_prev = tudg_eval(s_g, 0.0);  // (not a.g0: the table's own value, so that an empty column gives exactly 0)
+  // Downwelling at the surface is blind to everything above the depth where G has dropped to 2^-27 of G(0) times the
+  // column's Planck dynamic range at this wavenumber (what is dropped is at most that transmission times the largest
+  // Planck radiance, what is kept is of the order of the smallest): once every lane is there the wave stops evaluating G.
+  double g_floor;
+  {
+    const float b_hot = planck_f32(c1x3, x, a.c2l2e_over_Tmax), b_cold = planck_f32(c1x3, x, a.c2l2e_over_Tmin);
+    const float r = __builtin_amdgcn_logf(b_hot / b_cold);  // log2
+    const float y_opq = (b_cold > 0.f && r == r && r < 1e30f) ? TUD_OPAQUE_Y + 1.0f + fmaxf(r, 0.f) : 3.0e38f;
+    g_floor = a.g0 * (double)__builtin_amdgcn_exp2f(-fminf(y_opq, 120.0f));
+  }
+  bool down_live = nd > 0;  // wave-uniform
+
+  // ---- transmittance and upwelling of PB (altitude, slant) pairs bottom-up (:346-356); the first block also carries the
+  //      downwelling --------------------------------------------------------------------------------------------------------
+  for (int p0 = 0; p0 < npair; p0 += PB) {
+    float cp[PB], mup[PB];
+    int cntp[PB];
+    unsigned mw[PB][TUD_MAX_LAYERS / 32];
+    int cnt_max = 0;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {  // wave-uniform constants of the block's pairs
+      const int p = p0 + j < npair ? p0 + j : p0;
+      const int ia = p / a.n_mu, im = p - ia * a.n_mu;
+      cp[j] = a.mu_c[im];
+      mup[j] = a.mu[im];
+      cntp[j] = p0 + j < npair ? a.count[ia] : 0;
+#pragma unroll
+      for (int w = 0; w < TUD_MAX_LAYERS / 32; ++w) mw[j][w] = p0 + j < npair ? a.mask[ia][w] : 0u;
+      cnt_max = cntp[j] > cnt_max ? cntp[j] : cnt_max;
+    }
+    float sp[PB], Lu[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) { sp[j] = 0.f; Lu[j] = 0.f; }
+    const bool first = p0 == 0;
+    float nxt[TUD_STAGE];
+#pragma unroll
+    for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(t < nL ? t : nL - 1) * a.ld];
+    for (int kc = 0; kc < nL; kc += TUD_STAGE) {
+#pragma unroll
+      for (int t = 0; t < TUD_STAGE; ++t) s_stage[t][threadIdx.x] = nxt[t];
+#pragma unroll
+      for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(kc + TUD_STAGE + t < nL ? kc + TUD_STAGE + t : nL - 1) * a.ld];
+      const int k_hi = kc + TUD_STAGE < nL ? kc + TUD_STAGE : nL;
+      for (int k = kc; k < k_hi; ++k) {
+        const float od = s_stage[k - kc][threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+          const unsigned w = k < 32 ? mw[j][0] : k < 64 ? mw[j][1] : k < 96 ? mw[j][2] : mw[j][3];
+          if ((w >> (k & 31)) & 1u) sp[j] += od;
+        }
+        const bool up = k < cnt_max, dn = first && down_live && k < nd;  // wave-uniform
+        if (!up && !dn) continue;
+        const float B = planck_f32(c1x3, x, c2l2e_of(k));
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+          if (k < cntp[j]) {
+            // t Lu + (1-t) B: thin lanes through the emissivity, thick lanes through the transmittance (the other way round
+            // each form cancels); one form only where the whole wave agrees
+            const float y = od * cp[j];
+            const bool thin = y > -TUD_THIN_Y;
+#if TUDG_PAIR_BALLOT
+            const unsigned long long tb = __ballot(thin);
+            if (tb == ~0ull) Lu[j] = fmaf(em_thin(y), B - Lu[j], Lu[j]);
+            else if (tb == 0ull) Lu[j] = fmaf(__builtin_amdgcn_exp2f(y), Lu[j] - B, B);
+            else
+#endif
+            Lu[j] = thin ? fmaf(em_thin(y), B - Lu[j], Lu[j]) : fmaf(__builtin_amdgcn_exp2f(y), Lu[j] - B, B);
+          }
+        }
+        if (dn) {
+          S += (double)od;
+          const double g = tudg_eval(s_g, S);
+          acc = fmaf(B, (float)(g_prev - g), acc);
+          g_prev = g;
+          if (__ballot(g > g_floor) == 0ull) down_live = false;
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        if (p0 + j < npair) {
+          const size_t o = (size_t)(p0 + j) * (size_t)a.ld_out + (size_t)i;
+          a.tau[o] = a.return_od ? sp[j] * mup[j] : __builtin_amdgcn_exp2f(sp[j] * cp[j]);
+          a.Lu[o] = Lu[j];
+        }
+      }
+    }
+  }
+  if (live) a.Ld[i] = (S != S) ? __builtin_nanf("") : acc * a.inv_wsum;  // a NaN optical depth poisons the sum, as in the reference
+}
+
+// Several sensor altitudes and slant paths, the usual case of prefix masks (altitudes on an ascending height grid: the layers
+// with Z <= zs are the first count(zs) ones). The reference runs the SAME upwelling recurrence for every altitude -- only the
+// number of layers differs (:352-356) -- and tau's sum is then a running sum too, so one recurrence per SLANT serves every
+// altitude: its value after count(zs) layers is that altitude's L-up, stored the moment the pass gets there. Cost per layer:
+// Planck once + one recurrence per slant (the reference's main caller: 9 altitudes, 1 slant -- 9 passes' worth of work
+// before, barely more than one now). Bit-identical to running the pairs one by one. Non-prefix masks (a height grid that is
+// not ascending) take tud_g_pairs_kernel.
+template <int NMU>
+__global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
+  __shared__ double s_g[TUDG_NINT * 8];
+  __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots
+  for (int t = threadIdx.x; t < TUDG_NINT * 4; t += 256) reinterpret_cast<double2*>(s_g)[t] = reinterpret_cast<const double2*>(a.gtab)[t];
+  const long long i_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_raw < a.g.n;
+  const long long i = live ? i_raw : a.g.n - 1;  // dead lanes shadow the last point: ballots stay wave-wide
+  const int nL = a.n_layers;
+  const float* __restrict__ od_col = a.OD + i;
+  float nxt[TUD_STAGE];
+#pragma unroll
+  for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(t < nL ? t : nL - 1) * a.ld];
+  const double x = grid_x(a.g, a.g.offset + i);
+  const double x100 = x * 100.0;
+  const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
+  const int lane_id = threadIdx.x & 63;
+  const double ct_a = a.c2l2e_over_T[lane_id < nL ? lane_id : 0];
+  const double ct_b = a.c2l2e_over_T[lane_id + 64 < nL ? lane_id + 64 : 0];
+  auto c2l2e_of = [&](int k) -> double {  // k is wave-uniform
+    const double v = k < 64 ? ct_a : ct_b;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), k & 63);
+    return __hiloint2double(hi, lo);
+  };
+  __syncthreads();  // the table is in LDS
+
+  const int nd = a.n_down, n_alt = a.n_alt, n_mu = a.n_mu;
+  int cnt_max = 0;
+  unsigned long long snap_lo = 0ull, snap_hi = 0ull;  // bit c: some altitude's column has c layers (c <= 128; 128 itself is caught at the end)
+  for (int ia = 0; ia < n_alt; ++ia) {
+    const int c = a.count[ia];
+    cnt_max = c > cnt_max ? c : cnt_max;
+    if (c < 64) snap_lo |= 1ull << c; else if (c < 128) snap_hi |= 1ull << (c - 64);
+  }
+  float cm[NMU], mum[NMU], Lu[NMU];
+#pragma unroll
+  for (int m = 0; m < NMU; ++m) { cm[m] = a.mu_c[m < n_mu ? m : 0]; mum[m] = a.mu[m < n_mu ? m : 0]; Lu[m] = 0.f; }
+  float s_run = 0.f, acc = 0.f;
+  double S = 0.0, g_prev = tudg_eval(s_g, 0.0);
+  double g_floor;
+  {
+    const float b_hot = planck_f32(c1x3, x, a.c2l2e_over_Tmax), b_cold = planck_f32(c1x3, x, a.c2l2e_over_Tmin);
+    const float r = __builtin_amdgcn_logf(b_hot / b_cold);  // log2
+    const float y_opq = (b_cold > 0.f && r == r && r < 1e30f) ? TUD_OPAQUE_Y + 1.0f + fmaxf(r, 0.f) : 3.0e38f;
+    g_floor = a.g0 * (double)__builtin_amdgcn_exp2f(-fminf(y_opq, 120.0f));
+  }
+  // every altitude whose column has c layers gets its outputs now
+  auto snapshot = [&](int c) {
+    if (c < 128 && !(((c < 64 ? snap_lo : snap_hi) >> (c & 63)) & 1ull)) return;
+    for (int ia = 0; ia < n_alt; ++ia) {
+      if (a.count[ia] != c || !live) continue;
+#pragma unroll
+      for (int m = 0; m < NMU; ++m) {
+        if (m < n_mu) {
+          const size_t o = (size_t)(ia * n_mu + m) * (size_t)a.ld_out + (size_t)i;
+          a.tau[o] = a.return_od ? s_run * mum[m] : __builtin_amdgcn_exp2f(s_run * cm[m]);
+          a.Lu[o] = Lu[m];
+        }
+      }
+    }
+  };
+  snapshot(0);
+  bool down_live = nd > 0;  // wave-uniform
+  for (int kc = 0; kc < nL; kc += TUD_STAGE) {
+#pragma unroll
+    for (int t = 0; t < TUD_STAGE; ++t) s_stage[t][threadIdx.x] = nxt[t];
+#pragma unroll
+    for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(kc + TUD_STAGE + t < nL ? kc + TUD_STAGE + t : nL - 1) * a.ld];
+    const int k_hi = kc + TUD_STAGE < nL ? kc + TUD_STAGE : nL;
+    for (int k = kc; k < k_hi; ++k) {
+      const float od = s_stage[k - kc][threadIdx.x];
+      const bool up = k < cnt_max, dn = down_live && k < nd;  // wave-uniform
+      if (!up && !dn) continue;
+      const float B = planck_f32(c1x3, x, c2l2e_of(k));
+      if (up) {
+        s_run += od;
+#pragma unroll
+        for (int m = 0; m < NMU; ++m) {
+          if (m < n_mu) {
+            const float y = od * cm[m];
+            Lu[m] = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - Lu[m], Lu[m]) : fmaf(__builtin_amdgcn_exp2f(y), Lu[m] - B, B);
+          }
+        }
+        snapshot(k + 1);
+      }
+      if (dn) {
+        S += (double)od;
+        const double g = tudg_eval(s_g, S);
+        acc = fmaf(B, (float)(g_prev - g), acc);
+        g_prev = g;
+        if (__ballot(g > g_floor) == 0ull) down_live = false;
+      }
+    }
+  }
+  if (live) a.Ld[i] = (S != S) ? __builtin_nanf("") : acc * a.inv_wsum;
+}
+
 // Host side of G: piecewise Chebyshev interpolants of degree TUDG_DEG in fp64, stored as monomials in (S - mid).
 #include <map>
 #include <mutex>
@@ -846,7 +1080,13 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
     if (tudg_table(n_angle, &gt)) return 1;
     a.gtab = gt.dev; a.g_nint = TUDG_NINT; a.g0 = gt.g0;
     const long long blocks = (a.g.n + 255) / 256;
-    hipLaunchKernelGGL(tud_g_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    bool prefix = true;  // every altitude's mask = its first count layers?
+    for (int ia = 0; ia < n_alt && prefix; ++ia)
+      for (int k = 0; k < n_layers; ++k)
+        if ((mask_h[(size_t)ia * n_layers + k] != 0) != (k < a.count[ia])) { prefix = false; break; }
+    if (n_alt * n_mu == 1) hipLaunchKernelGGL(tud_g_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else if (prefix) hipLaunchKernelGGL(tud_g_snap_kernel<TUD_MAX_MU>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(tud_g_pairs_kernel<TUDG_PB>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     RTX_LAUNCH_CHECK();
     return 0;
   }

@@ -670,7 +670,8 @@ def test_alternative_line_sum_kernels_agree(kernel):
 # --------------------------------------------------------------------- TUD: randomised configurations
 def test_tud_random_configurations_vs_oracle():
     """rtx_tud against the oracle on random columns: 1..70 layers, several sensor altitudes (also non-monotone ones and
-    ones below the surface layer), slant paths, 1..40 angles (more than one block of streams), returnOD, and optical
+    ones below the surface layer; ascending height grids -- one recurrence per slant, snapshots per altitude -- and
+    shuffled ones -- pairs in blocks), slant paths, 1..40 angles (more than one block of streams), returnOD, and optical
     depths whose magnitude changes by layer and along the spectrum so that waves are thin, thick, mixed and opaque --
     the paths the kernel selects per (wave, layer), the opaque-slab start and the staged OD loads."""
     import torch
@@ -681,6 +682,8 @@ def test_tud_random_configurations_vs_oracle():
         nL = int(rng.integers(1, 71))
         n = int(rng.integers(700, 3000))
         Z = np.sort(rng.uniform(0.0, 60.0, nL))
+        if trial % 4 == 2:
+            Z = rng.permutation(Z)  # a height grid that is not ascending: the Z <= zs masks are no prefixes (tau: mask, L-up: count)
         T = rng.uniform(190.0, 310.0, nL)
         lo = float(rng.uniform(500.0, 5500.0))
         grid = engine.Grid(lo, lo + 2.0, n)
@@ -694,11 +697,13 @@ def test_tud_random_configurations_vs_oracle():
         OD = (scale[:, None] * shape[None, :]).astype(np.float32)
         if trial % 3 == 0:
             OD[:, rng.integers(0, n, 20)] = 0.0
-        nalt = int(rng.integers(1, 4))
+        nalt = int(rng.integers(1, 6))
         alts = rng.uniform(-1.0, 70.0, nalt)
         if trial % 4 == 1:
             alts = np.array([500.0])
         theta = float(rng.choice([0.0, 0.3, 1.1]))
+        if trial % 3 == 1:
+            theta = np.array([0.0, 0.5, 1.2])  # with up to 5 altitudes: more (altitude, slant) pairs than one block
         nA = int(rng.choice([1, 2, 7, 30, 33, 40]))
         ret_od = bool(trial % 5 == 2)
         tau, Lu, Ld, (nZ, nMu) = engine.tud(torch.as_tensor(OD, device="cuda"), grid, T, Z, Altitudes=alts, theta_r=theta,
@@ -706,7 +711,7 @@ def test_tud_random_configurations_vs_oracle():
         tr, ur, dr = ref.tud_from_od(X, OD.astype(np.float64).T, T, Z, Altitudes=alts, theta_r=theta, N_angle=nA, returnOD=ret_od)
         tau_h = tau.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1).reshape(np.shape(tr))
         Lu_h = Lu.double().cpu().numpy().reshape(nZ, nMu, -1).transpose(2, 0, 1).reshape(np.shape(ur))
-        tag = (trial, nL, nalt, theta, nA, ret_od)
+        tag = (trial, nL, nalt, str(theta), nA, ret_od)
         if ret_od:
             assert rel_err(tau_h, tr) <= TOL_L, tag
         else:

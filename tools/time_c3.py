@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--n", type=int, default=5500000)
 ap.add_argument("--layers", type=int, default=32)
+ap.add_argument("--n-alt", type=int, default=1, help="sensor altitudes (the reference's main caller asks for 9)")
 ap.add_argument("--shard", type=str, default="", help="R/N: time rank R's wavenumber shard of N, with the FULL line table")
 ap.add_argument("--mf-scale", type=float, default=1.0, help="scale the mixing ratios (1e-4: an optically thin column, tau ~ 0.5-1 between lines)")
 args = ap.parse_args()
@@ -29,13 +30,14 @@ T, Z = atm["Ts"], atm["Zs"]
 w, p_atm = engine.layer_weights_od(lines.species, T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
 qr, mass = engine.species_factors(lines.species, T)
 OD = torch.empty((args.layers, grid.n), dtype=torch.float32, device="cuda")
+alts = (500,) if args.n_alt == 1 else tuple(np.linspace(Z[2], Z[-1], args.n_alt))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 tv, tt = [], []
 for it in range(args.reps + 2):
     ev[0].record()
     engine.voigt_sum(lines, grid, T, p_atm, w, out_f32=OD, qratio=qr, mass=mass)
     ev[1].record()
-    tau, Lu, Ld, _ = engine.tud(OD, grid, T, Z)
+    tau, Lu, Ld, _ = engine.tud(OD, grid, T, Z, Altitudes=alts)
     ev[2].record()
     torch.cuda.synchronize()
     if it >= 2:
