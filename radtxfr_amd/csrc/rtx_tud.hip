@@ -175,6 +175,7 @@ struct TudArgs {
   const double* gtab;                  // angle-summed transmission function G (tud_g_kernel): [g_nint][8] doubles
   int g_nint;
   double g0;                           // G(0) = sum of the quadrature weights
+  int planck_nodes;                    // 1: B_k across a wave's 64 wavenumbers by a parabola through 3 of them (host-checked: error < 1e-10)
 };
 
 // 1 - exp(-OD*sec) = 1 - 2^y (y = OD*c <= 0), accurate to ~1e-7 RELATIVE also when it is tiny.
@@ -593,6 +594,42 @@ __device__ __forceinline__ double tudg_eval(const double* __restrict__ s_g, doub
   return r;
 }
 
+// Planck radiances of a layer across the 64 consecutive wavenumbers of a wave: B(nu, T_k) is so smooth in nu that a parabola
+// through its values at lanes 0, 32 and 63 reproduces it to < 1e-10 on grids this fine (the host checks
+// (4/nu_min + c2/T_min) x 63 steps <= 7e-3 and clears TudArgs.planck_nodes otherwise). The three values of EVERY layer are
+// computed in one go with lane = layer (lane k already holds layer k's 100 c2 log2e / T): 3 Planck evaluations per wave
+// instead of one per layer, and the layer loop rebuilds B_k with two FMAs on coefficients fetched by v_readlane.
+struct PlanckNodes {
+  float c0, c1, c2;  // lane k: coefficients of layer k in t = lane / 63 (n_layers <= 64)
+  float t;
+};
+__device__ __forceinline__ PlanckNodes planck_nodes_setup(const TudArgs& a, double ct) {
+  PlanckNodes P;
+  const long long i0w = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);  // raw index of lane 0 (may lie past the shard: grid_x extrapolates)
+  const float t1 = 32.0f / 63.0f;
+  float b[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const double xn = grid_x(a.g, a.g.offset + i0w + (n == 0 ? 0 : n == 1 ? 32 : 63));
+    const double x100 = xn * 100.0;
+    b[n] = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, xn, ct);
+  }
+  // Newton form through (0, b0), (t1, b1), (1, b2), expanded to monomials
+  const float d01 = (b[1] - b[0]) / t1, d12 = (b[2] - b[1]) / (1.0f - t1);
+  P.c2 = d12 - d01;
+  P.c1 = d01 - P.c2 * t1;
+  P.c0 = b[0];
+  P.t = (float)(threadIdx.x & 63) * (1.0f / 63.0f);
+  return P;
+}
+__device__ __forceinline__ float planck_nodes_eval(const PlanckNodes& P, int k) {  // k wave-uniform, < 64
+  const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c0), k));
+  const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c1), k));
+  const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c2), k));
+  return fmaf(fmaf(c2, P.t, c1), P.t, c0);
+}
+
+template <bool PN>
 __global__ __launch_bounds__(256) void tud_g_kernel(TudArgs a) {
   __shared__ double s_g[TUDG_NINT * 8];
   __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots
@@ -622,6 +659,8 @@ __global__ __launch_bounds__(256) void tud_g_kernel(TudArgs a) {
     const unsigned w = k < 32 ? mk0 : k < 64 ? mk1 : k < 96 ? mk2 : mk3;
     return (w >> (k & 31)) & 1u;
   };
+  PlanckNodes PNd;
+  if (PN) PNd = planck_nodes_setup(a, ct_a);
   __syncthreads();  // the table is in LDS
 
   // ---- every further (altitude, slant factor) pair: transmittance + upwelling bottom-up (:346-356) ----------
@@ -634,7 +673,7 @@ __global__ __launch_bounds__(256) void tud_g_kernel(TudArgs a) {
       const float od = od_col[(size_t)k * a.ld];
       if ((a.mask[ia][k >> 5] >> (k & 31)) & 1u) s += od;
       if (k < cnt) {
-        const float B = planck_f32(c1x3, x, c2l2e_of(k));
+        const float B = PN ? planck_nodes_eval(PNd, k) : planck_f32(c1x3, x, c2l2e_of(k));
         const float y = od * c;
         Lu = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - Lu, Lu) : fmaf(__builtin_amdgcn_exp2f(y), Lu - B, B);
       }
@@ -673,7 +712,7 @@ __global__ __launch_bounds__(256) void tud_g_kernel(TudArgs a) {
       if (mask0_bit(k)) s0 += od;
       const bool up = k < cnt0, dn = down_live && k < nd;  // wave-uniform
       if (!up && !dn) continue;
-      const float B = planck_f32(c1x3, x, c2l2e_of(k));
+      const float B = PN ? planck_nodes_eval(PNd, k) : planck_f32(c1x3, x, c2l2e_of(k));
       if (up) {
         const float y = od * c0;
         Lu0 = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - Lu0, Lu0) : fmaf(__builtin_amdgcn_exp2f(y), Lu0 - B, B);
@@ -831,7 +870,7 @@ __global__ __launch_bounds__(256) void tud_g_pairs_kernel(TudArgs a) {
 // Planck once + one recurrence per slant (the reference's main caller: 9 altitudes, 1 slant -- 9 passes' worth of work
 // before, barely more than one now). Bit-identical to running the pairs one by one. Non-prefix masks (a height grid that is
 // not ascending) take tud_g_pairs_kernel.
-template <int NMU>
+template <int NMU, bool PN>
 __global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
   __shared__ double s_g[TUDG_NINT * 8];
   __shared__ float s_stage[TUD_STAGE][256];  // each thread's own slots
@@ -855,6 +894,8 @@ __global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), k & 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), k & 63);
     return __hiloint2double(hi, lo);
   };
+  PlanckNodes PNd;
+  if (PN) PNd = planck_nodes_setup(a, ct_a);
   __syncthreads();  // the table is in LDS
 
   const int nd = a.n_down, n_alt = a.n_alt, n_mu = a.n_mu;
@@ -904,7 +945,7 @@ __global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
       const float od = s_stage[k - kc][threadIdx.x];
       const bool up = k < cnt_max, dn = down_live && k < nd;  // wave-uniform
       if (!up && !dn) continue;
-      const float B = planck_f32(c1x3, x, c2l2e_of(k));
+      const float B = PN ? planck_nodes_eval(PNd, k) : planck_f32(c1x3, x, c2l2e_of(k));
       if (up) {
         s_run += od;
 #pragma unroll
@@ -1084,8 +1125,18 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
     for (int ia = 0; ia < n_alt && prefix; ++ia)
       for (int k = 0; k < n_layers; ++k)
         if ((mask_h[(size_t)ia * n_layers + k] != 0) != (k < a.count[ia])) { prefix = false; break; }
-    if (n_alt * n_mu == 1) hipLaunchKernelGGL(tud_g_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
-    else if (prefix) hipLaunchKernelGGL(tud_g_snap_kernel<TUD_MAX_MU>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    // B_k across a wave by a parabola through three of its wavenumbers (PlanckNodes) where that is exact to 1e-10:
+    // |d ln B / d nu| <= 4/nu + c2/T, and the parabola's error is 0.008 (that x 63 steps)^3
+    const double nu_lo = grid->xmin + grid->step * (double)grid->offset;
+    const bool pn = n_layers <= 64 && nu_lo > 0.0 && (4.0 / nu_lo + RT_C2 * 100.0 / t_min) * 63.0 * grid->step <= 7e-3;
+    a.planck_nodes = pn ? 1 : 0;
+    if (n_alt * n_mu == 1) {
+      if (pn) hipLaunchKernelGGL(tud_g_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(tud_g_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else if (prefix) {
+      if (pn) hipLaunchKernelGGL((tud_g_snap_kernel<TUD_MAX_MU, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((tud_g_snap_kernel<TUD_MAX_MU, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
     else hipLaunchKernelGGL(tud_g_pairs_kernel<TUDG_PB>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     RTX_LAUNCH_CHECK();
     return 0;

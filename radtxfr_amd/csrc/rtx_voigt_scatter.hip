@@ -36,7 +36,7 @@
 #include <vector>
 
 #ifndef RTX_SC_ABLATE
-#define RTX_SC_ABLATE 0  /* timing experiments: 1 = no band rows, 2 = no band rows and no edge rows, 3 = no far rows */
+#define RTX_SC_ABLATE 0  /* timing experiments: bit 0 = no band rows, 1 = no far rows, 2 = no point-by-point rows in the drain, 3 = no entries at all, 4 = no window-edge rows (and no entries for lines that have nothing else) */
 #endif
 #ifndef RTX_SC_ASYM
 #define RTX_SC_ASYM 1
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(S
     const unsigned m_far = (RTX_SC_ABLATE & 2) ? 0u : (m_in & ~m_near);           // smooth: Chebyshev nodes of the rows
     const unsigned m_bd = m_reach & m_band;                                       // band rows
     const unsigned m_pp = m_in & m_near & ~m_band;                                 // near-zone rows wholly inside the window
-    const unsigned m_ed = m_reach & ~m_in & ~m_band;                              // rows cut by a window edge
+    const unsigned m_ed = (RTX_SC_ABLATE & 16) ? 0u : (m_reach & ~m_in & ~m_band);  // rows cut by a window edge
     const float ub = (float)(ia - qi0);  // integer-valued
     constexpr unsigned ALL_ROWS = (1u << ROWS) - 1u;
     if (RTX_SC_STAMP && __ballot(m_pp == 0xffffffffu)) t_ph[7] += 1;  // (forces the masks, i.e. the record loads, before the stamp)
