@@ -600,32 +600,46 @@ __device__ __forceinline__ double tudg_eval(const double* __restrict__ s_g, doub
 // computed in one go with lane = layer (lane k already holds layer k's 100 c2 log2e / T): 3 Planck evaluations per wave
 // instead of one per layer, and the layer loop rebuilds B_k with two FMAs on coefficients fetched by v_readlane.
 struct PlanckNodes {
-  float c0, c1, c2;  // lane k: coefficients of layer k in t = lane / 63 (n_layers <= 64)
+  float c0, c1, c2;     // lane k: coefficients of layer k in t = lane / 63
+  float c0b, c1b, c2b;  // ... of layer k + 64
   float t;
 };
-__device__ __forceinline__ PlanckNodes planck_nodes_setup(const TudArgs& a, double ct) {
+__device__ __forceinline__ PlanckNodes planck_nodes_setup(const TudArgs& a, double ct_a, double ct_b, int nL) {
   PlanckNodes P;
   const long long i0w = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);  // raw index of lane 0 (may lie past the shard: grid_x extrapolates)
   const float t1 = 32.0f / 63.0f;
-  float b[3];
+  float b[3], bb[3];
 #pragma unroll
   for (int n = 0; n < 3; ++n) {
     const double xn = grid_x(a.g, a.g.offset + i0w + (n == 0 ? 0 : n == 1 ? 32 : 63));
     const double x100 = xn * 100.0;
-    b[n] = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, xn, ct);
+    const double c1x3 = RT_C1 * (x100 * x100 * x100) * 1e4;
+    b[n] = planck_f32(c1x3, xn, ct_a);
+    bb[n] = nL > 64 ? planck_f32(c1x3, xn, ct_b) : 0.f;  // wave-uniform branch
   }
   // Newton form through (0, b0), (t1, b1), (1, b2), expanded to monomials
-  const float d01 = (b[1] - b[0]) / t1, d12 = (b[2] - b[1]) / (1.0f - t1);
-  P.c2 = d12 - d01;
-  P.c1 = d01 - P.c2 * t1;
-  P.c0 = b[0];
+  {
+    const float d01 = (b[1] - b[0]) / t1, d12 = (b[2] - b[1]) / (1.0f - t1);
+    P.c2 = d12 - d01; P.c1 = d01 - P.c2 * t1; P.c0 = b[0];
+  }
+  {
+    const float d01 = (bb[1] - bb[0]) / t1, d12 = (bb[2] - bb[1]) / (1.0f - t1);
+    P.c2b = d12 - d01; P.c1b = d01 - P.c2b * t1; P.c0b = bb[0];
+  }
   P.t = (float)(threadIdx.x & 63) * (1.0f / 63.0f);
   return P;
 }
-__device__ __forceinline__ float planck_nodes_eval(const PlanckNodes& P, int k) {  // k wave-uniform, < 64
-  const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c0), k));
-  const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c1), k));
-  const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c2), k));
+__device__ __forceinline__ float planck_nodes_eval(const PlanckNodes& P, int k) {  // k wave-uniform
+  float c0, c1, c2;
+  if (k < 64) {
+    c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c0), k));
+    c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c1), k));
+    c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c2), k));
+  } else {
+    c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c0b), k - 64));
+    c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c1b), k - 64));
+    c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P.c2b), k - 64));
+  }
   return fmaf(fmaf(c2, P.t, c1), P.t, c0);
 }
 
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(256) void tud_g_kernel(TudArgs a) {
     return (w >> (k & 31)) & 1u;
   };
   PlanckNodes PNd;
-  if (PN) PNd = planck_nodes_setup(a, ct_a);
+  if (PN) PNd = planck_nodes_setup(a, ct_a, ct_b, nL);
   __syncthreads();  // the table is in LDS
 
   // ---- every further (altitude, slant factor) pair: transmittance + upwelling bottom-up (:346-356) ----------
@@ -895,7 +909,7 @@ __global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
     return __hiloint2double(hi, lo);
   };
   PlanckNodes PNd;
-  if (PN) PNd = planck_nodes_setup(a, ct_a);
+  if (PN) PNd = planck_nodes_setup(a, ct_a, ct_b, nL);
   __syncthreads();  // the table is in LDS
 
   const int nd = a.n_down, n_alt = a.n_alt, n_mu = a.n_mu;
@@ -1128,7 +1142,7 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
     // B_k across a wave by a parabola through three of its wavenumbers (PlanckNodes) where that is exact to 1e-10:
     // |d ln B / d nu| <= 4/nu + c2/T, and the parabola's error is 0.008 (that x 63 steps)^3
     const double nu_lo = grid->xmin + grid->step * (double)grid->offset;
-    const bool pn = n_layers <= 64 && nu_lo > 0.0 && (4.0 / nu_lo + RT_C2 * 100.0 / t_min) * 63.0 * grid->step <= 7e-3;
+    const bool pn = nu_lo > 0.0 && (4.0 / nu_lo + RT_C2 * 100.0 / t_min) * 63.0 * grid->step <= 7e-3;
     a.planck_nodes = pn ? 1 : 0;
     if (n_alt * n_mu == 1) {
       if (pn) hipLaunchKernelGGL(tud_g_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -7,7 +7,7 @@
 // Re w(x+iy) by Weideman's rational expansion (misc/hapi.py:9812-9827), real arithmetic:
 //   Z = (L + i z)/(L - i z),  w = 2 p(Z)/(L - i z)^2 + (1/sqrt(pi))/(L - i z),  p = 24-term polynomial.
 // p is evaluated as pe(Z^2) + Z*po(Z^2): two independent 12-step chains instead of one 24-step chain (the serial chain
-// stalled the band rows); in fp32 each half by the real two-term recurrence below, in fp64 by complex Horner steps.
+// stalled the band rows), each half by the real two-term recurrence below.
 template <typename F>
 __device__ __forceinline__ F weideman_re(F x, F y) {
   const F L = (F)W24_L;
@@ -27,12 +27,13 @@ __device__ __forceinline__ F weideman_re(F x, F y) {
   const F Wr = fma(Zr, Zr, -(Zi * Zi)), Wi = (F)2 * Zr * Zi;  // W = Z^2
   // coef[] is in polyval order: p = sum_k coef[k] Z^(23-k); odd powers <-> even k
   F or_, oi, er, ei;  // po(W): coefficients of Z^23, Z^21, ... (k = 0, 2, ...); pe(W): Z^22, Z^20, ... (k = 1, 3, ...)
-  if constexpr (sizeof(F) == 4) {
+  {
     // The coefficients are REAL: q(W) = sum c_k W^k is the remainder of the division by W^2 - r W + s (r = 2 Re W,
     // s = |W|^2), i.e. the real recurrence b_k = c_k + r b_{k+1} - s b_{k+2} and q = c_0 - s b_2 + b_1 W: two FMAs per
-    // coefficient instead of the four of a complex Horner step (47 operations for both halves instead of 88). |W| < 1
-    // in the whole band (y >= 1), so rounding errors are damped; against the fp64 reference over the band of the
-    // main pass (y >= 1, |z| < 8 or y < 6) the result is within 1.8e-6, the same as the complex Horner form (1.9e-6).
+    // coefficient instead of the four of a complex Horner step (47 operations for both halves instead of 88). |W| <= 1
+    // (= 1 only on the real axis, y = 0), so rounding errors are not amplified: in fp32, over the band of the main pass
+    // (y >= 1, |z| < 8 or y < 6), the result is within 1.8e-6 of the fp64 reference, the same as the complex Horner form
+    // (1.9e-6); in fp64, over 1e-6 <= y < 1, within 1.5e-15 (absolute) of numpy.polyval.
     const F r = (F)2 * Wr, ns = -fma(Wr, Wr, Wi * Wi);
     F ob1 = coef[0], ob2 = (F)0, eb1 = coef[1], eb2 = (F)0;
 #pragma unroll
@@ -43,16 +44,6 @@ __device__ __forceinline__ F weideman_re(F x, F y) {
     }
     or_ = fma(ob1, Wr, fma(ns, ob2, coef[22])); oi = ob1 * Wi;
     er = fma(eb1, Wr, fma(ns, eb2, coef[23])); ei = eb1 * Wi;
-  } else {
-    or_ = coef[0]; oi = (F)0; er = coef[1]; ei = (F)0;
-#pragma unroll
-    for (int k = 2; k < 24; k += 2) {
-      const F t0 = fma(or_, Wr, fma(-oi, Wi, coef[k]));
-      const F t1 = fma(or_, Wi, oi * Wr);
-      const F t2 = fma(er, Wr, fma(-ei, Wi, coef[k + 1]));
-      const F t3 = fma(er, Wi, ei * Wr);
-      or_ = t0; oi = t1; er = t2; ei = t3;
-    }
   }
   const F pr = fma(or_, Zr, fma(-oi, Zi, er));  // p = pe + Z*po
   const F pi = fma(or_, Zi, fma(oi, Zr, ei));
