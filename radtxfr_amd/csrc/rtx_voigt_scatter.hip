@@ -113,13 +113,26 @@ __device__ __forceinline__ RowGeom row_geom(int qi0, int qlo, int qhi, int qzw, 
 // One band row: region test + Weideman for lanes inside |x|+y<15, far-wing formula elsewhere, window-masked.
 // A line with y < 1 belongs to the CORE64 pass (same predicate on the same fp32 record in both passes).
 // The record fields may live in SGPRs (scalar visit) or be wave-uniform VGPR values (nodal kernel).
-template <bool CORE64>
+// MODE 0: the fp32 main pass (the band lanes of y < 1 lines are left to the fp64 pass); MODE 1: the fp64 pass, which adds
+// ONLY those lanes; MODE 2: both in one (the nodal kernel's instantiation for layers that hold y < 1 lines).
+template <int MODE>
 __device__ __forceinline__ void band_row(const ScArgs& a, const LineRec64* __restrict__ rec64, int slot, const LineRec& q, float u, int i,
                                          float zw_f, float ulo, float uhi, bool small_y, float& num, float& rden, bool& touched) {
+  constexpr bool CORE64 = MODE == 1;
   float x;
   farwing(u, q, x, num, rden);
   const bool in_band = fabsf(u) <= zw_f;
-  if (CORE64 ? small_y : !small_y) {
+  if (MODE == 2 && small_y) {
+    // Doppler-dominated line: the reference's switch and its Weideman value in fp64 on every lane of the row; lanes
+    // outside |x| + y < 15 keep the far-wing value
+    const LineRec64 Q = rec64[slot];
+    const double sg = grid_x(a.g, a.g.offset + (long long)i);
+    const double x64 = -((Q.sg0 - sg) * Q.cte);
+    if (fabs(x64) + Q.y < 15.0) {
+      num = (float)(Q.A * weideman_re<double>(x64, Q.y));
+      rden = 1.0f;
+    }
+  } else if (CORE64 ? small_y : !small_y) {
     // hum1_wei's switch |x|+y < 15 (:9840): fp32 decides unless a lane sits within 2e-3 of it; those
     // lanes repeat the test exactly as the reference forms it, in fp64: x = -Im Z1 = -((sg0 - sg)*cte)
     const float s32 = fabsf(x) + q.y;
@@ -241,7 +254,7 @@ __device__ __forceinline__ void visit_line(const ScArgs& a, const LineRec* __res
     for (int r = zb; r <= ze; ++r) {
       float* p = acc + r * 64 + lane;
       float num, rden;
-      band_row<CORE64>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
+      band_row<CORE64 ? 1 : 0>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
       p[0] = fmaf(num, rden, p[0]);
     }
   }
@@ -387,7 +400,10 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #ifndef SC_ENT_CAP
 #define SC_ENT_CAP 32  // point-by-point entries per wave (64 B each). With two waves per workgroup: 16 -> 2.02 ms, 24 -> 1.99, 32 -> 1.96, 48 -> 2.03
 #endif
-__global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a) {
+// SMALLY: the instantiation for layers that hold Doppler-dominated (y < 1) lines: their band lanes take the fp64 Weideman
+// value right here (band_row MODE 2) instead of in a second pass over the layer.
+template <bool SMALLY>
+__device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const int k) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
   __shared__ float s_acc[SC_NW][TILE];              // one private tile per wave (near rows)
@@ -396,10 +412,8 @@ __global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(S
   // after the last drain the entry lists are dead: wave w keeps its row-level sums [ROWS][8] in its list
   static_assert(RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "row sums fit in one wave's entry list");
 
-  const int b = blockIdx.x;
   const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
   if (tile >= a.n_tiles) return;
-  const int k = blockIdx.y;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const long long n = a.g.n;
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(S
         m_bd &= m_bd - 1u;
         float* p = acc + r * 64 + lane;
         float num, rden;
-        band_row<false>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
+        band_row<SMALLY ? 2 : 0>(a, rec64, slot, q, u0 + (float)(64 * r), ia + 64 * r + lane, zw_f, ulo, uhi, small_y, num, rden, touched);
         p[0] = fmaf(num, rden, p[0]);
       }
       STAMP(5);  // band rows
@@ -602,8 +616,8 @@ __global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(S
   static_assert(SC_NW == 1 || SC_NW == 2 || SC_NW == 4, "one, two or four waves per workgroup");
   for (int o = threadIdx.x; o < ROWS * CHEB_N; o += 64 * SC_NW) {  // o = r * CHEB_N + jj
     float v = reinterpret_cast<const float*>(&s_ent[0][0][0])[o];
-    if (SC_NW >= 2) v += reinterpret_cast<const float*>(&s_ent[1][0][0])[o];
-    if (SC_NW == 4) v += reinterpret_cast<const float*>(&s_ent[2][0][0])[o] + reinterpret_cast<const float*>(&s_ent[3][0][0])[o];
+    if constexpr (SC_NW >= 2) v += reinterpret_cast<const float*>(&s_ent[1][0][0])[o];
+    if constexpr (SC_NW == 4) v += reinterpret_cast<const float*>(&s_ent[2][0][0])[o] + reinterpret_cast<const float*>(&s_ent[3][0][0])[o];
     s_nodsum[o >> 3][o & 7] = v;
   }
   __syncthreads();
@@ -620,8 +634,8 @@ __global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(S
 #pragma unroll
       for (int jj = 0; jj < CHEB_N; ++jj) f = fmaf(wl[jj], s_nodsum[r][jj], f);
       float pp = s_acc[0][t];
-      if (SC_NW >= 2) pp += s_acc[1][t];
-      if (SC_NW == 4) pp += s_acc[2][t] + s_acc[3][t];
+      if constexpr (SC_NW >= 2) pp += s_acc[1][t];
+      if constexpr (SC_NW == 4) pp += s_acc[2][t] + s_acc[3][t];
       const float v = pp + f;
       if (i < (long long)ib) {
         const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
@@ -636,6 +650,27 @@ __global__ __launch_bounds__(64 * SC_NW, RTX_SC_WAVES) void voigt_nodal_kernel(S
       unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * SC_NW + wave) * SC_NSTAMP;
       for (int i = 0; i < SC_NSTAMP; ++i) o[i] = (unsigned long long)t_ph[i];
     }
+  }
+}
+
+// SMALLY = false: one workgroup per tile slot; layers that hold y < 1 lines (per-layer flag from the prologue) are left to
+// the other instantiation. SMALLY = true: a grid-stride loop over the tile slots with 1/16 of the workgroups -- when a layer
+// has no such line (every layer of C3) each workgroup returns at once, and launching one per tile just to do that cost
+// 30 us per step. The stride is a multiple of 8, so a workgroup's slots stay on its XCD (xcd_tile).
+#ifndef RTX_SC_WAVES_SMALLY
+#define RTX_SC_WAVES_SMALLY 4
+#endif
+template <bool SMALLY>
+__global__ __launch_bounds__(64 * SC_NW, SMALLY ? RTX_SC_WAVES_SMALLY : RTX_SC_WAVES) void voigt_nodal_kernel(ScArgs a) {
+  const int k = blockIdx.y;
+  if ((a.smally[k] != 0) != SMALLY) return;
+  if (SMALLY) {
+    for (int b = blockIdx.x; b < 8 * a.tiles_per_xcd; b += gridDim.x) {
+      nodal_tile<true>(a, b, k);
+      __syncthreads();  // the tile copies are reused by the next slot
+    }
+  } else {
+    nodal_tile<false>(a, blockIdx.x, k);
   }
 }
 
@@ -671,8 +706,13 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   // RADTXFR_DEBUG_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, to time the kernel at reduced occupancy
   static int lds_pad = -1;
   if (lds_pad < 0) { const char* e = getenv("RADTXFR_DEBUG_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
-  if (nodal) hipLaunchKernelGGL(voigt_nodal_kernel, dim3(8 * a.tiles_per_xcd, n_layers), dim3(64 * SC_NW), (size_t)lds_pad, st, a);
-  else hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  if (nodal) {
+    hipLaunchKernelGGL((voigt_nodal_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(64 * SC_NW), (size_t)lds_pad, st, a);
+    RTX_LAUNCH_CHECK();
+    hipLaunchKernelGGL((voigt_nodal_kernel<true>), dim3(8 * ((a.tiles_per_xcd + 15) / 16), n_layers), dim3(64 * SC_NW), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
+  }
   RTX_LAUNCH_CHECK();
 #if RTX_SC_STAMP
   {
@@ -690,7 +730,9 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
             h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w);
   }
 #endif
-  hipLaunchKernelGGL((voigt_scatter_kernel<true>), dim3(8 * ((a.tiles_per_xcd + 15) / 16), n_layers), dim3(256), 0, st, a);
-  RTX_LAUNCH_CHECK();
+  if (!nodal) {  // the point-by-point formulation keeps its separate fp64 pass
+    hipLaunchKernelGGL((voigt_scatter_kernel<true>), dim3(8 * ((a.tiles_per_xcd + 15) / 16), n_layers), dim3(256), 0, st, a);
+    RTX_LAUNCH_CHECK();
+  }
   return 0;
 }
