@@ -1,6 +1,6 @@
 // Voigt line-sum, "scatter into per-wave LDS tiles" formulations: the default nodal kernel and the point-by-point
-// scatter kernel it grew out of, kept as its cross-check and as the fp64 pass for Doppler-dominated lines (rtx_voigt.hip
-// holds the dispatcher; both kernels share the record layout and the Weideman code of rtx_voigt_math.h).
+// scatter kernel it grew out of, kept as its cross-check (RADTXFR_VOIGT_KERNEL=scatter; rtx_voigt.hip holds the
+// dispatcher; both kernels share the record layout and the Weideman code of rtx_voigt_math.h).
 //
 // A workgroup owns a tile of SC_TILE consecutive grid points of one layer; EACH LINE IS TAKEN BY EXACTLY ONE
 // WAVE, which accumulates the line into ITS OWN copy of the tile in LDS (plain ds_read/add/ds_write: no other
@@ -10,7 +10,7 @@
 //
 // Two kernels:
 //  voigt_scatter_kernel<CORE64>  every row a window reaches is evaluated point by point (7 VALU + v_rcp_f32 + one
-//                                LDS read/write per row and line). CORE64 = true is the fp64 pass for y < 1 lines.
+//                                LDS read/write per row and line). CORE64 = true is its fp64 pass for y < 1 lines.
 //  voigt_nodal_kernel            (default main pass) the same, but only for the rows NEAR a line: within
 //                                SC_NEAR rows of its centre, in its Weideman band, or cut by a window edge.
 //                                On every other row the line is a smooth far wing -- the rational far-wing form of
