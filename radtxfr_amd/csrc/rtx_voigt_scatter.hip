@@ -391,6 +391,10 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 // fills its groups of 8 members better; one wave per workgroup: the same), the Weideman halves by the real two-term recurrence
 // (2.25 -> 2.17). Measured slower: one compaction for full and partial members together with only the last group mixed (15
 // spilled registers, 2.08 vs 1.93), the next entry read ahead in the final drain (2.00 vs 1.93).
+// A single segment level on top of that -- full members whose centre is >= 8 rows outside the tile evaluated at 8 nodes per
+// 4-row segment (2.7e-7), a quarter of their evaluations, sums carried to the row nodes by a constant 4 x 8 x 8 matrix in the
+// final stage: 2.02 vs 1.95 (distance 6 / 10: 2.03 / 2.04). The extra compaction pass and one more spilled register cost
+// more than the ~40 % of the members it takes off the row level save, as the three-level tree had shown with four waves.
 #ifndef RTX_SC_WAVES
 #define RTX_SC_WAVES 6
 #endif
