@@ -73,6 +73,10 @@ def load():
         raise RtxError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C radtxfr_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: it carries its own HIP runtime, and the library must bind to THAT copy (the one that owns the tensors'
+    # device memory and streams). Loaded the other way round -- the library before torch, as a build() followed by a smoke()
+    # in one process does -- the process ends up with two runtimes and the library's sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         try:
