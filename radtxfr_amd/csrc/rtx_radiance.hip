@@ -9,6 +9,11 @@
 // in LDS (fp64 Planck, once per (a,t)) and streams the [nE][nA][nT] slab with coalesced stores.
 // The ILS never builds the reference's dense (nS,nX,nB) temporary: each band only visits the grid
 // points under its own weight function.
+#include <map>
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
+
 #include "rtx_common.h"
 
 #define RT_C1 1.19104295315e-16
@@ -330,6 +335,197 @@ __global__ __launch_bounds__(256) void ils_columns4_kernel(IlsArgs a) {
   }
 }
 
+// ---- triangle ILS over a large materialised Y in ONE pass over its rows ----------------------------------------------------
+// ils_columns4_kernel streams a band's support per workgroup; neighbouring bands' supports overlap (sigma = 1.6 band
+// spacings: every row lies under ~3.2 triangles), so every row of Y comes from HBM ~3.2 times -- 14.5 GB for C4's 4.56 GB
+// input. Here a workgroup owns ILS_CH consecutive rows x 256 columns, reads them once and keeps the sums of every band
+// that reaches the chunk (up to ILS_CAP at a time in registers; the weight of a row under a band is uniform over the
+// lanes); the chunks' partial sums go to a workspace and ils_rows_reduce_kernel adds a band's chunks in a fixed order
+// (deterministic: no atomics) and normalises. A chunk reached by more than ILS_SLOTS bands raises a flag and the reduce
+// kernel then redoes its band the old way, so the result never depends on the band list being well behaved.
+#ifndef ILS_CH
+#define ILS_CH 1024
+#endif
+#ifndef ILS_CAP
+#define ILS_CAP 4  // bands per register pass (C4, ms: 6 -> 1.22, 5 -> 1.08, 4 -> 1.06; a chunk reached by more runs again over rows that are in cache by then)
+#endif
+#define ILS_SLOTS 12
+struct IlsRowsArgs {
+  IlsArgs a;
+  float* P;    // [n_chunks][ILS_SLOTS][nS]
+  float* Wt;   // [n_chunks][ILS_SLOTS]
+  int* b0;     // [n_chunks] first band of the chunk, [n_chunks .. 2 n_chunks) number of bands
+  int* overflow;
+  int n_chunks;
+};
+
+__global__ __launch_bounds__(256) void ils_rows_kernel(IlsRowsArgs r) {
+  const IlsArgs& a = r.a;
+  const int chunk = blockIdx.x;
+  const long long r0 = (long long)chunk * ILS_CH, r1 = r0 + ILS_CH < a.nx ? r0 + ILS_CH : a.nx;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long col4 = (long long)blockIdx.y * 64 + lane;
+  const long long nS4 = a.nS >> 2, ld4 = a.ldY >> 2;
+  const bool live = col4 < nS4;
+  const float4* Y4 = reinterpret_cast<const float4*>(a.Y) + (live ? col4 : 0);
+  __shared__ int s_b0, s_b1;
+  __shared__ float4 s_red[4][64];
+  __shared__ float s_w[4];
+  if (threadIdx.x == 0) { s_b0 = a.nB; s_b1 = -1; }
+  __syncthreads();
+  const double x_lo = ils_x(a, r0), x_hi = ils_x(a, r1 - 1);
+  for (int b = threadIdx.x; b < a.nB; b += 256) {  // bands whose open support (c - s, c + s) meets the chunk
+    const double c = a.centre[b], sg = a.sigma[b];
+    if (c + sg > x_lo && c - sg < x_hi) { atomicMin(&s_b0, b); atomicMax(&s_b1, b); }
+  }
+  __syncthreads();
+  const int b0 = s_b0, n_act = s_b1 - b0 + 1;
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    r.b0[chunk] = b0;
+    r.b0[r.n_chunks + chunk] = n_act > 0 ? n_act : 0;
+    if (n_act > ILS_SLOTS) *r.overflow = 1;
+  }
+  if (n_act <= 0) return;
+  const int n_use = n_act < ILS_SLOTS ? n_act : ILS_SLOTS;
+  for (int g0 = 0; g0 < n_use; g0 += ILS_CAP) {
+    double cj[ILS_CAP];
+    float isj[ILS_CAP], wsum[ILS_CAP];
+    float4 acc[ILS_CAP];
+#pragma unroll
+    for (int j = 0; j < ILS_CAP; ++j) {
+      const bool v = g0 + j < n_use;
+      cj[j] = v ? a.centre[b0 + g0 + j] : 0.0;
+      isj[j] = v ? 1.0f / (float)a.sigma[b0 + g0 + j] : 0.0f;
+      if (!v) isj[j] = __builtin_inff();  // 1 - |d| inf = -inf -> weight 0 (x = 0 is never a grid point of a band's support)
+      wsum[j] = 0.f;
+      acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long long i = r0 + wave; i < r1; i += 16) {  // four rows in flight per wave
+      float4 y[4];
+      float xd[4][ILS_CAP];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const long long it = i + 4 * t;
+        const bool in = it < r1;
+        y[t] = in ? Y4[it * ld4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const double x = ils_x(a, in ? it : r1 - 1);
+#pragma unroll
+        for (int j = 0; j < ILS_CAP; ++j) {
+          const float w = 1.0f - fabsf((float)(x - cj[j])) * isj[j];  // tri(), :1236-1239
+          xd[t][j] = (in && w > 0.f) ? w : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int j = 0; j < ILS_CAP; ++j) {
+          const float w = xd[t][j];
+          wsum[j] += w;
+          acc[j].x = fmaf(w, y[t].x, acc[j].x); acc[j].y = fmaf(w, y[t].y, acc[j].y);
+          acc[j].z = fmaf(w, y[t].z, acc[j].z); acc[j].w = fmaf(w, y[t].w, acc[j].w);
+        }
+      }
+    }
+    // the four waves' sums, slot by slot, in a fixed order
+#pragma unroll
+    for (int j = 0; j < ILS_CAP; ++j) {
+      if (g0 + j >= n_use) break;
+      s_red[wave][lane] = acc[j];
+      if (lane == 0) s_w[wave] = wsum[j];
+      __syncthreads();
+      if (wave == 0) {
+        if (live) {
+          float4 v;
+          v.x = (s_red[0][lane].x + s_red[1][lane].x) + (s_red[2][lane].x + s_red[3][lane].x);
+          v.y = (s_red[0][lane].y + s_red[1][lane].y) + (s_red[2][lane].y + s_red[3][lane].y);
+          v.z = (s_red[0][lane].z + s_red[1][lane].z) + (s_red[2][lane].z + s_red[3][lane].z);
+          v.w = (s_red[0][lane].w + s_red[1][lane].w) + (s_red[2][lane].w + s_red[3][lane].w);
+          reinterpret_cast<float4*>(r.P + ((size_t)chunk * ILS_SLOTS + (g0 + j)) * (size_t)a.nS)[col4] = v;
+        }
+        if (blockIdx.y == 0 && lane == 0) r.Wt[(size_t)chunk * ILS_SLOTS + (g0 + j)] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ils_rows_reduce_kernel(IlsRowsArgs r) {
+  const IlsArgs& a = r.a;
+  if (*r.overflow) {  // some chunk is reached by more bands than the workspace holds: this band the per-band way
+    // (ils_columns4_kernel's body; the launch geometry is the same)
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long col4 = (long long)blockIdx.y * 64 + lane;
+    const long long nS4 = a.nS >> 2, ld4 = a.ldY >> 2;
+    const double c = a.centre[b], sg = a.sigma[b];
+    const long long lo = ils_bound(a, c - sg, 1), hi = ils_bound(a, c + sg, 0);
+    const bool live = col4 < nS4;
+    const float4* Y4 = reinterpret_cast<const float4*>(a.Y) + (live ? col4 : 0);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wsum = 0.f;
+    for (long long i = lo + wave; i < hi; i += 4) {
+      const float w0 = ils_weight(0, ils_x(a, i), c, sg);
+      const float4 y0 = Y4[i * ld4];
+      wsum += w0;
+      acc.x = fmaf(w0, y0.x, acc.x); acc.y = fmaf(w0, y0.y, acc.y); acc.z = fmaf(w0, y0.z, acc.z); acc.w = fmaf(w0, y0.w, acc.w);
+    }
+    __shared__ float4 s_acc[4][64];
+    __shared__ float s_w[4];
+    s_acc[wave][lane] = acc;
+    if (lane == 0) s_w[wave] = wsum;
+    __syncthreads();
+    if (wave == 0 && live) {
+      const float N = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+      float4 v;
+      v.x = ((s_acc[0][lane].x + s_acc[1][lane].x) + (s_acc[2][lane].x + s_acc[3][lane].x)) / N;
+      v.y = ((s_acc[0][lane].y + s_acc[1][lane].y) + (s_acc[2][lane].y + s_acc[3][lane].y)) / N;
+      v.z = ((s_acc[0][lane].z + s_acc[1][lane].z) + (s_acc[2][lane].z + s_acc[3][lane].z)) / N;
+      v.w = ((s_acc[0][lane].w + s_acc[1][lane].w) + (s_acc[2][lane].w + s_acc[3][lane].w)) / N;
+      reinterpret_cast<float4*>(a.Yout + (size_t)b * a.nS)[col4] = v;
+    }
+    return;
+  }
+  const int b = blockIdx.x;
+  const long long col4 = (long long)blockIdx.y * 256 + threadIdx.x;  // one thread per float4 column group
+  const long long nS4 = a.nS >> 2;
+  if (col4 >= nS4) return;
+  const double c = a.centre[b], sg = a.sigma[b];
+  const long long lo = ils_bound(a, c - sg, 1), hi = ils_bound(a, c + sg, 0);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float N = 0.f;
+  if (hi > lo) {
+    const int c0 = (int)(lo / ILS_CH), c1 = (int)((hi - 1) / ILS_CH);
+    for (int ch = c0; ch <= c1; ++ch) {
+      const int slot = b - r.b0[ch];
+      if (slot < 0 || slot >= r.b0[r.n_chunks + ch]) continue;
+      const float4 v = reinterpret_cast<const float4*>(r.P + ((size_t)ch * ILS_SLOTS + slot) * (size_t)a.nS)[col4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      N += r.Wt[(size_t)ch * ILS_SLOTS + slot];
+    }
+  }
+  float4 o;
+  o.x = acc.x / N; o.y = acc.y / N; o.z = acc.z / N; o.w = acc.w / N;  // an empty support: 0/0 = NaN, like the reference
+  reinterpret_cast<float4*>(a.Yout + (size_t)b * a.nS)[col4] = o;
+}
+
+// grow-only workspace of the one-pass form, per device
+static int ils_rows_workspace(size_t bytes, void** out) {
+  static std::mutex mu;
+  static std::map<int, std::pair<void*, size_t>> ws;
+  int dev = 0;
+  RTX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto& e = ws[dev];
+  if (e.second < bytes) {
+    if (e.first) RTX_HIP(hipFree(e.first));
+    e.first = nullptr; e.second = 0;
+    RTX_HIP(hipMalloc(&e.first, bytes));
+    e.second = bytes;
+  }
+  *out = e.first;
+  return 0;
+}
+
 extern "C" int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t nx, const float* Y, int64_t nS, int64_t ldY,
                        int nB, const double* centre_d, const double* sigma_d, float* Y_out, void* stream) {
   if (kind != 0 && kind != 1) RTX_FAIL("kind must be 0 (triangle) or 1 (Gaussian)");
@@ -348,8 +544,28 @@ extern "C" int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t 
   hipStream_t st = (hipStream_t)stream;
   if (nS <= 4) hipLaunchKernelGGL(ils_points_kernel<4>, dim3(nB), dim3(256), 0, st, a);
   else if (nS <= 16) hipLaunchKernelGGL(ils_points_kernel<16>, dim3(nB), dim3(256), 0, st, a);
-  else if (nS % 4 == 0 && ldY % 4 == 0 && (((uintptr_t)Y | (uintptr_t)Y_out) % 16 == 0))
-    hipLaunchKernelGGL(ils_columns4_kernel, dim3(nB, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, a);
+  else if (nS % 4 == 0 && ldY % 4 == 0 && (((uintptr_t)Y | (uintptr_t)Y_out) % 16 == 0)) {
+    // the one-pass form where a band's support is long against a chunk (its partial sums then cost little next to Y
+    // itself) and Y is big enough to matter; otherwise one workgroup per band and column block
+    static int one_pass = -1;
+    if (one_pass < 0) { const char* e = getenv("RADTXFR_ILS_KERNEL"); one_pass = (e && !strcmp(e, "bands")) ? 0 : 1; }
+    const long long n_chunks = (nx + ILS_CH - 1) / ILS_CH;
+    if (one_pass && kind == 0 && nx >= (long long)nB * 2 * ILS_CH && (double)nx * (double)nS >= 3.0e7 && n_chunks < (1 << 20)) {
+      IlsRowsArgs r;
+      r.a = a; r.n_chunks = (int)n_chunks;
+      const size_t nP = (size_t)n_chunks * ILS_SLOTS * (size_t)nS, nW = (size_t)n_chunks * ILS_SLOTS;
+      void* base = nullptr;
+      if (ils_rows_workspace((nP + nW) * sizeof(float) + (2 * (size_t)n_chunks + 1) * sizeof(int), &base)) return 1;
+      r.P = (float*)base; r.Wt = r.P + nP; r.b0 = (int*)(r.Wt + nW); r.overflow = r.b0 + 2 * n_chunks;
+      RTX_HIP(hipMemsetAsync(r.overflow, 0, sizeof(int), st));
+      hipLaunchKernelGGL(ils_rows_kernel, dim3((unsigned)n_chunks, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, r);
+      RTX_LAUNCH_CHECK();
+      // (band, column block): 256 float4 column groups per workgroup when reducing, 64 when a band is redone the old way
+      hipLaunchKernelGGL(ils_rows_reduce_kernel, dim3(nB, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, r);
+    } else {
+      hipLaunchKernelGGL(ils_columns4_kernel, dim3(nB, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, a);
+    }
+  }
   else hipLaunchKernelGGL(ils_columns_kernel, dim3(nB, (unsigned)((nS + 63) / 64)), dim3(256), 0, st, a);
   RTX_LAUNCH_CHECK();
   return 0;

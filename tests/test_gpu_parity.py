@@ -317,6 +317,26 @@ def test_ils_many_spectra_and_edges(rt):
     assert rel_err(yo[ok], yr[ok]) <= TOL_L
 
 
+def test_ils_one_pass_over_large_spectra(rt):
+    """The one-pass triangle ILS (ils_rows_kernel: every row of Y read once, partial sums per row chunk, fixed-order
+    reduce) on a Y large enough to take it -- 300 000 rows x 256 spectra, 128 and 256 bands, default and widened
+    triangles (more bands per chunk than one register pass holds; at fwhm_sf = 4 more than the workspace holds: the
+    per-band fallback) -- against the reference's dense formulation on sampled columns."""
+    import torch
+    rng = np.random.default_rng(20261013)
+    nx, nS = 300000, 256
+    X = np.linspace(690.0, 1480.0, nx)
+    Y = (rng.uniform(0.5, 10.0, (1, nS)) * (1.0 + 0.3 * np.sin(X[:, None] * rng.uniform(0.01, 0.5, (1, nS))))).astype(np.float32)
+    Yd = torch.as_tensor(Y, device="cuda")
+    cols = rng.choice(nS, 6, replace=False)
+    for res, sf in ((None, 1.0), (2, 1.0), (None, 2.2), (None, 4.0)):
+        xo, yo = rt.ILS_MAKO(X, Yd, resFactor=res, fwhm_sf=sf)
+        yo = yo.cpu().numpy() if hasattr(yo, "cpu") else np.asarray(yo)
+        xr, yr = ref.ILS_MAKO(X, Y[:, cols].astype(np.float64), resFactor=res, fwhm_sf=sf)
+        assert np.array_equal(np.asarray(xo), xr)
+        assert rel_err(yo[:, cols], yr) <= TOL_L, (res, sf)
+
+
 # ------------------------------------------------------------ C1 / C2 of BASELINE.json at full size
 def test_c1_planck_beer_lambert(rt):
     """Config C1: X = linspace(700,1400,700), surface at 287.87 K with eps = 1, one layer at 287.87 K with
