@@ -335,30 +335,37 @@ __global__ __launch_bounds__(256) void ils_columns4_kernel(IlsArgs a) {
   }
 }
 
-// ---- triangle ILS over a large materialised Y in ONE pass over its rows ----------------------------------------------------
-// ils_columns4_kernel streams a band's support per workgroup; neighbouring bands' supports overlap (sigma = 1.6 band
-// spacings: every row lies under ~3.2 triangles), so every row of Y comes from HBM ~3.2 times -- 14.5 GB for C4's 4.56 GB
-// input. Here a workgroup owns ILS_CH consecutive rows x 256 columns, reads them once and keeps the sums of every band
-// that reaches the chunk (up to ILS_CAP at a time in registers; the weight of a row under a band is uniform over the
-// lanes); the chunks' partial sums go to a workspace and ils_rows_reduce_kernel adds a band's chunks in a fixed order
-// (deterministic: no atomics) and normalises. A chunk reached by more than ILS_SLOTS bands raises a flag and the reduce
-// kernel then redoes its band the old way, so the result never depends on the band list being well behaved.
+// ---- ILS over a large materialised Y in ONE pass over its rows ---------------------------------------------------------------
+// ils_columns4_kernel streams a band's support per workgroup; neighbouring bands' supports overlap (triangle: sigma = 1.6
+// band spacings, every row lies under ~3.2 of them; Gaussian: 14 sigma either side, ~28), so every row of Y comes from HBM
+// that many times -- 14.5 GB for C4's 4.56 GB input with the triangle, 128 GB with the Gaussian. Here a workgroup owns
+// ILS_CH consecutive rows x 256 columns, reads them once from HBM and keeps the sums of every band that reaches the chunk
+// (ILS_CAP / ILS_CAP_GAUSS at a time in registers, further passes over the chunk come from the cache; the weight of a row under a band is
+// uniform over the lanes); the chunks' partial sums go to a workspace and ils_rows_reduce_kernel adds a band's chunks in a
+// fixed order (deterministic: no atomics) and normalises. A chunk reached by more bands than the workspace has slots for
+// raises a flag and the reduce kernel then redoes its band the old way, so the result never depends on the band list being
+// well behaved.
 #ifndef ILS_CH
 #define ILS_CH 1024
 #endif
 #ifndef ILS_CAP
-#define ILS_CAP 4  // bands per register pass (C4, ms: 6 -> 1.22, 5 -> 1.08, 4 -> 1.06; a chunk reached by more runs again over rows that are in cache by then)
+#define ILS_CAP 4  // bands per register pass (C4 triangle, ms: 6 -> 1.22, 5 -> 1.08, 4 -> 1.06)
 #endif
-#define ILS_SLOTS 12
+#ifndef ILS_CAP_GAUSS
+#define ILS_CAP_GAUSS 10  // the Gaussian's ~30 bands per chunk: 3 passes
+#endif
+#define ILS_SLOTS_TRI 12
+#define ILS_SLOTS_GAUSS 40
 struct IlsRowsArgs {
   IlsArgs a;
-  float* P;    // [n_chunks][ILS_SLOTS][nS]
-  float* Wt;   // [n_chunks][ILS_SLOTS]
+  float* P;    // [n_chunks][slots][nS]
+  float* Wt;   // [n_chunks][slots]
   int* b0;     // [n_chunks] first band of the chunk, [n_chunks .. 2 n_chunks) number of bands
   int* overflow;
-  int n_chunks;
+  int n_chunks, slots;
 };
 
+template <int KIND, int CAP>
 __global__ __launch_bounds__(256) void ils_rows_kernel(IlsRowsArgs r) {
   const IlsArgs& a = r.a;
   const int chunk = blockIdx.x;
@@ -374,61 +381,91 @@ __global__ __launch_bounds__(256) void ils_rows_kernel(IlsRowsArgs r) {
   if (threadIdx.x == 0) { s_b0 = a.nB; s_b1 = -1; }
   __syncthreads();
   const double x_lo = ils_x(a, r0), x_hi = ils_x(a, r1 - 1);
-  for (int b = threadIdx.x; b < a.nB; b += 256) {  // bands whose open support (c - s, c + s) meets the chunk
+  for (int b = threadIdx.x; b < a.nB; b += 256) {  // bands whose open support (c - R, c + R) meets the chunk
     const double c = a.centre[b], sg = a.sigma[b];
-    if (c + sg > x_lo && c - sg < x_hi) { atomicMin(&s_b0, b); atomicMax(&s_b1, b); }
+    double z0sq;
+    bool dead;
+    const double R = ils_reach(a, c, sg, z0sq, dead);
+    if (!dead && c + R > x_lo && c - R < x_hi) { atomicMin(&s_b0, b); atomicMax(&s_b1, b); }
   }
   __syncthreads();
   const int b0 = s_b0, n_act = s_b1 - b0 + 1;
   if (blockIdx.y == 0 && threadIdx.x == 0) {
     r.b0[chunk] = b0;
     r.b0[r.n_chunks + chunk] = n_act > 0 ? n_act : 0;
-    if (n_act > ILS_SLOTS) *r.overflow = 1;
+    if (n_act > r.slots) *r.overflow = 1;
   }
   if (n_act <= 0) return;
-  const int n_use = n_act < ILS_SLOTS ? n_act : ILS_SLOTS;
-  for (int g0 = 0; g0 < n_use; g0 += ILS_CAP) {
-    double cj[ILS_CAP];
-    float isj[ILS_CAP], wsum[ILS_CAP];
-    float4 acc[ILS_CAP];
+  const int n_use = n_act < r.slots ? n_act : r.slots;
+  for (int g0 = 0; g0 < n_use; g0 += CAP) {
+    double cj[CAP], isd[CAP], z0[CAP];
+    float isj[CAP], wsum[CAP];
+    float4 acc[CAP];
 #pragma unroll
-    for (int j = 0; j < ILS_CAP; ++j) {
+    for (int j = 0; j < CAP; ++j) {
       const bool v = g0 + j < n_use;
-      cj[j] = v ? a.centre[b0 + g0 + j] : 0.0;
-      isj[j] = v ? 1.0f / (float)a.sigma[b0 + g0 + j] : 0.0f;
-      if (!v) isj[j] = __builtin_inff();  // 1 - |d| inf = -inf -> weight 0 (x = 0 is never a grid point of a band's support)
+      const double c = v ? a.centre[b0 + g0 + j] : 0.0, sg = v ? a.sigma[b0 + g0 + j] : 1.0;
+      double z0sq;
+      bool dead;
+      (void)ils_reach(a, c, sg, z0sq, dead);
+      cj[j] = c;
+      z0[j] = z0sq;
+      isd[j] = 1.0 / sg;
+      // triangle: 1/sigma; Gaussian: 1/(sigma sqrt(2 pi)). An unused slot or a band the reference gives 0/0: weight 0
+      isj[j] = KIND == 0 ? (v ? 1.0f / (float)sg : __builtin_inff()) : ((v && !dead) ? 1.0f / ((float)sg * 2.5066282746310002f) : 0.0f);
       wsum[j] = 0.f;
       acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (long long i = r0 + wave; i < r1; i += 16) {  // four rows in flight per wave
-      float4 y[4];
-      float xd[4][ILS_CAP];
+    // A row's weight under a band is the same for every lane: lane l computes the weights of ITS row of a 64-row block
+    // (wave w's rows: first + w + 4 l) for the CAP bands once, and the row loop fetches row t's weights with
+    // v_readlane -- one weight evaluation per row and band instead of 64 identical ones (the Gaussian's fp64 argument
+    // and exponential were 3/4 of that kernel's instructions).
+    for (long long blk = r0; blk < r1; blk += 256) {
+      const long long my_row = blk + wave + 4 * lane;
+      const bool my_in = my_row < r1;
+      const double xr = ils_x(a, my_in ? my_row : r1 - 1);
+      float wv[CAP];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const long long it = i + 4 * t;
-        const bool in = it < r1;
-        y[t] = in ? Y4[it * ld4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const double x = ils_x(a, in ? it : r1 - 1);
-#pragma unroll
-        for (int j = 0; j < ILS_CAP; ++j) {
-          const float w = 1.0f - fabsf((float)(x - cj[j])) * isj[j];  // tri(), :1236-1239
-          xd[t][j] = (in && w > 0.f) ? w : 0.f;
+      for (int j = 0; j < CAP; ++j) {
+        float w;
+        if (KIND == 0) {
+          w = 1.0f - fabsf((float)(xr - cj[j])) * isj[j];  // tri(), :1236-1239
+        } else {
+          const double z = (xr - cj[j]) * isd[j];
+          w = __expf((float)(-0.5 * (z * z - z0[j]))) * isj[j];  // g(), ILS_MAKO.py:24, relative to the nearest point for a band outside the grid
         }
+        wv[j] = (my_in && w > 0.f) ? w : 0.f;
+        wsum[j] += wv[j];  // per lane; summed over the lanes below
       }
+      const long long n_rows = (r1 - blk - wave + 3) / 4;  // rows of this wave in the block
+      const int nt = n_rows > 64 ? 64 : (n_rows > 0 ? (int)n_rows : 0);
+      for (int t = 0; t < nt; t += 4) {  // four rows in flight
+        float4 y[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+        for (int u = 0; u < 4; ++u) {
+          const long long it = blk + wave + 4 * (t + u);
+          y[u] = (t + u < nt) ? Y4[it * ld4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-        for (int j = 0; j < ILS_CAP; ++j) {
-          const float w = xd[t][j];
-          wsum[j] += w;
-          acc[j].x = fmaf(w, y[t].x, acc[j].x); acc[j].y = fmaf(w, y[t].y, acc[j].y);
-          acc[j].z = fmaf(w, y[t].z, acc[j].z); acc[j].w = fmaf(w, y[t].w, acc[j].w);
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int j = 0; j < CAP; ++j) {
+            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv[j]), (t + u) & 63));  // 0 past the last row
+            acc[j].x = fmaf(w, y[u].x, acc[j].x); acc[j].y = fmaf(w, y[u].y, acc[j].y);
+            acc[j].z = fmaf(w, y[u].z, acc[j].z); acc[j].w = fmaf(w, y[u].w, acc[j].w);
+          }
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) {  // the wave's weight sum: over its lanes, fixed order
+      float v = wsum[j];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      wsum[j] = __shfl(v, 0);
+    }
     // the four waves' sums, slot by slot, in a fixed order
 #pragma unroll
-    for (int j = 0; j < ILS_CAP; ++j) {
+    for (int j = 0; j < CAP; ++j) {
       if (g0 + j >= n_use) break;
       s_red[wave][lane] = acc[j];
       if (lane == 0) s_w[wave] = wsum[j];
@@ -440,9 +477,9 @@ __global__ __launch_bounds__(256) void ils_rows_kernel(IlsRowsArgs r) {
           v.y = (s_red[0][lane].y + s_red[1][lane].y) + (s_red[2][lane].y + s_red[3][lane].y);
           v.z = (s_red[0][lane].z + s_red[1][lane].z) + (s_red[2][lane].z + s_red[3][lane].z);
           v.w = (s_red[0][lane].w + s_red[1][lane].w) + (s_red[2][lane].w + s_red[3][lane].w);
-          reinterpret_cast<float4*>(r.P + ((size_t)chunk * ILS_SLOTS + (g0 + j)) * (size_t)a.nS)[col4] = v;
+          reinterpret_cast<float4*>(r.P + ((size_t)chunk * r.slots + (g0 + j)) * (size_t)a.nS)[col4] = v;
         }
-        if (blockIdx.y == 0 && lane == 0) r.Wt[(size_t)chunk * ILS_SLOTS + (g0 + j)] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        if (blockIdx.y == 0 && lane == 0) r.Wt[(size_t)chunk * r.slots + (g0 + j)] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
       }
       __syncthreads();
     }
@@ -451,20 +488,23 @@ __global__ __launch_bounds__(256) void ils_rows_kernel(IlsRowsArgs r) {
 
 __global__ __launch_bounds__(256) void ils_rows_reduce_kernel(IlsRowsArgs r) {
   const IlsArgs& a = r.a;
+  const int b = blockIdx.x;
+  const double c = a.centre[b], sg = a.sigma[b];
+  double z0sq;
+  bool dead;
+  const double R = ils_reach(a, c, sg, z0sq, dead);
+  const long long lo = dead ? 0 : ils_bound(a, c - R, 1), hi = dead ? 0 : ils_bound(a, c + R, 0);
   if (*r.overflow) {  // some chunk is reached by more bands than the workspace holds: this band the per-band way
-    // (ils_columns4_kernel's body; the launch geometry is the same)
-    const int b = blockIdx.x;
+    // (ils_columns4_kernel's arithmetic; the launch geometry is the same)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long col4 = (long long)blockIdx.y * 64 + lane;
     const long long nS4 = a.nS >> 2, ld4 = a.ldY >> 2;
-    const double c = a.centre[b], sg = a.sigma[b];
-    const long long lo = ils_bound(a, c - sg, 1), hi = ils_bound(a, c + sg, 0);
     const bool live = col4 < nS4;
     const float4* Y4 = reinterpret_cast<const float4*>(a.Y) + (live ? col4 : 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float wsum = 0.f;
     for (long long i = lo + wave; i < hi; i += 4) {
-      const float w0 = ils_weight(0, ils_x(a, i), c, sg);
+      const float w0 = ils_weight(a.kind, ils_x(a, i), c, sg, z0sq);
       const float4 y0 = Y4[i * ld4];
       wsum += w0;
       acc.x = fmaf(w0, y0.x, acc.x); acc.y = fmaf(w0, y0.y, acc.y); acc.z = fmaf(w0, y0.z, acc.z); acc.w = fmaf(w0, y0.w, acc.w);
@@ -485,12 +525,9 @@ __global__ __launch_bounds__(256) void ils_rows_reduce_kernel(IlsRowsArgs r) {
     }
     return;
   }
-  const int b = blockIdx.x;
   const long long col4 = (long long)blockIdx.y * 256 + threadIdx.x;  // one thread per float4 column group
   const long long nS4 = a.nS >> 2;
   if (col4 >= nS4) return;
-  const double c = a.centre[b], sg = a.sigma[b];
-  const long long lo = ils_bound(a, c - sg, 1), hi = ils_bound(a, c + sg, 0);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float N = 0.f;
   if (hi > lo) {
@@ -498,9 +535,9 @@ __global__ __launch_bounds__(256) void ils_rows_reduce_kernel(IlsRowsArgs r) {
     for (int ch = c0; ch <= c1; ++ch) {
       const int slot = b - r.b0[ch];
       if (slot < 0 || slot >= r.b0[r.n_chunks + ch]) continue;
-      const float4 v = reinterpret_cast<const float4*>(r.P + ((size_t)ch * ILS_SLOTS + slot) * (size_t)a.nS)[col4];
+      const float4 v = reinterpret_cast<const float4*>(r.P + ((size_t)ch * r.slots + slot) * (size_t)a.nS)[col4];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      N += r.Wt[(size_t)ch * ILS_SLOTS + slot];
+      N += r.Wt[(size_t)ch * r.slots + slot];
     }
   }
   float4 o;
@@ -550,15 +587,16 @@ extern "C" int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t 
     static int one_pass = -1;
     if (one_pass < 0) { const char* e = getenv("RADTXFR_ILS_KERNEL"); one_pass = (e && !strcmp(e, "bands")) ? 0 : 1; }
     const long long n_chunks = (nx + ILS_CH - 1) / ILS_CH;
-    if (one_pass && kind == 0 && nx >= (long long)nB * 2 * ILS_CH && (double)nx * (double)nS >= 3.0e7 && n_chunks < (1 << 20)) {
+    if (one_pass && nx >= (long long)nB * 2 * ILS_CH && (double)nx * (double)nS >= 3.0e7 && n_chunks < (1 << 20)) {
       IlsRowsArgs r;
-      r.a = a; r.n_chunks = (int)n_chunks;
-      const size_t nP = (size_t)n_chunks * ILS_SLOTS * (size_t)nS, nW = (size_t)n_chunks * ILS_SLOTS;
+      r.a = a; r.n_chunks = (int)n_chunks; r.slots = kind == 0 ? ILS_SLOTS_TRI : ILS_SLOTS_GAUSS;
+      const size_t nP = (size_t)n_chunks * r.slots * (size_t)nS, nW = (size_t)n_chunks * r.slots;
       void* base = nullptr;
       if (ils_rows_workspace((nP + nW) * sizeof(float) + (2 * (size_t)n_chunks + 1) * sizeof(int), &base)) return 1;
       r.P = (float*)base; r.Wt = r.P + nP; r.b0 = (int*)(r.Wt + nW); r.overflow = r.b0 + 2 * n_chunks;
       RTX_HIP(hipMemsetAsync(r.overflow, 0, sizeof(int), st));
-      hipLaunchKernelGGL(ils_rows_kernel, dim3((unsigned)n_chunks, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, r);
+      if (kind == 0) hipLaunchKernelGGL((ils_rows_kernel<0, ILS_CAP>), dim3((unsigned)n_chunks, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, r);
+      else hipLaunchKernelGGL((ils_rows_kernel<1, ILS_CAP_GAUSS>), dim3((unsigned)n_chunks, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, r);
       RTX_LAUNCH_CHECK();
       // (band, column block): 256 float4 column groups per workgroup when reducing, 64 when a band is redone the old way
       hipLaunchKernelGGL(ils_rows_reduce_kernel, dim3(nB, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, r);

@@ -335,6 +335,19 @@ def test_ils_one_pass_over_large_spectra(rt):
         xr, yr = ref.ILS_MAKO(X, Y[:, cols].astype(np.float64), resFactor=res, fwhm_sf=sf)
         assert np.array_equal(np.asarray(xo), xr)
         assert rel_err(yo[:, cols], yr) <= TOL_L, (res, sf)
+    # the Gaussian variant (ILS_MAKO.py): ~28 bands reach every row; on a grid that covers all 128 band centres, and on
+    # one that leaves some outside (their far tails average the grid's edge region)
+    from radtxfr_amd import ILS_MAKO as ilsg
+    for lo, hi in ((690.0, 1480.0), (800.0, 1250.0)):
+        Xg = np.linspace(lo, hi, nx)
+        xg, yg = ilsg.ILS_MAKO(Xg, Yd)
+        yg = yg.cpu().numpy() if hasattr(yg, "cpu") else np.asarray(yg)
+        with np.errstate(all="ignore"):
+            xr, yr = ref.ILS_MAKO_gauss(Xg, Y[:, cols].astype(np.float64))
+        assert np.array_equal(np.asarray(xg), xr)
+        assert np.array_equal(np.isnan(yg[:, cols]), np.isnan(yr))
+        ok = ~np.isnan(yr)
+        assert rel_err(yg[:, cols][ok], yr[ok]) <= TOL_L, (lo, hi)
 
 
 # ------------------------------------------------------------ C1 / C2 of BASELINE.json at full size
