@@ -79,11 +79,14 @@ __global__ __launch_bounds__(256) void apparent_radiance_kernel(RadArgs a, int l
   }
 }
 
-// One atmosphere, no dT axis (config C4): pure streaming, one spectral channel per workgroup-iteration,
-// 16-B loads/stores along the emissivity axis, Planck per thread in fp32 from an fp64 exponent.
+// One atmosphere, no dT axis (config C4): pure streaming. One spectral channel per WAVE-iteration, eight 16-B loads per lane
+// along the emissivity axis issued before the first is used (8 KB of a 2000-emissivity row in flight per wave), Planck per
+// lane in fp32 from an fp64 exponent. (One channel per workgroup-iteration with two dependent load/store pairs per thread:
+// 4.7 TB/s read + write; this form: see DESIGN.md 4.4.)
 __global__ __launch_bounds__(256) void apparent_radiance_row_kernel(RadArgs a) {
-  const long long nE4 = a.nE >> 2;
-  for (long long ix = blockIdx.x; ix < a.nX; ix += gridDim.x) {
+  const long long nE4 = a.nE >> 2;  // nE % 4 == 0 on this path
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long ix = (long long)blockIdx.x * 4 + wave; ix < a.nX; ix += (long long)gridDim.x * 4) {
     const double x = a.X[ix];
     const double x100 = x * 100.0;
     const float B = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, 100.0 * RT_C2 * 1.4426950408889634 / a.Ts[0]);
@@ -91,20 +94,25 @@ __global__ __launch_bounds__(256) void apparent_radiance_row_kernel(RadArgs a) {
     const float4* em = reinterpret_cast<const float4*>(a.emis + ix * a.nE);
     float4* L = reinterpret_cast<float4*>(a.L + ix * a.nE);
     float4* Ls = a.Ls ? reinterpret_cast<float4*>(a.Ls + ix * a.nE) : nullptr;
-    for (long long q = threadIdx.x; q < nE4; q += blockDim.x) {
-      const float4 e = em[q];
-      float4 ls, l;
-      ls.x = e.x * B + (1.0f - e.x) * Ld; ls.y = e.y * B + (1.0f - e.y) * Ld;
-      ls.z = e.z * B + (1.0f - e.z) * Ld; ls.w = e.w * B + (1.0f - e.w) * Ld;
-      l.x = tau * ls.x + La; l.y = tau * ls.y + La; l.z = tau * ls.z + La; l.w = tau * ls.w + La;
-      L[q] = l;
-      if (Ls) Ls[q] = ls;
-    }
-    for (long long ie = (nE4 << 2) + threadIdx.x; ie < a.nE; ie += blockDim.x) {  // ragged tail
-      const float e = a.emis[ix * a.nE + ie];
-      const float ls = e * B + (1.0f - e) * Ld;
-      a.L[ix * a.nE + ie] = tau * ls + La;
-      if (a.Ls) a.Ls[ix * a.nE + ie] = ls;
+    for (long long q0 = 0; q0 < nE4; q0 += 512) {
+      float4 e[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const long long q = q0 + lane + 64 * t;
+        e[t] = q < nE4 ? em[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const long long q = q0 + lane + 64 * t;
+        if (q < nE4) {
+          float4 ls, l;
+          ls.x = e[t].x * B + (1.0f - e[t].x) * Ld; ls.y = e[t].y * B + (1.0f - e[t].y) * Ld;
+          ls.z = e[t].z * B + (1.0f - e[t].z) * Ld; ls.w = e[t].w * B + (1.0f - e[t].w) * Ld;
+          l.x = tau * ls.x + La; l.y = tau * ls.y + La; l.z = tau * ls.z + La; l.w = tau * ls.w + La;
+          L[q] = l;
+          if (Ls) Ls[q] = ls;
+        }
+      }
     }
   }
 }
@@ -122,7 +130,8 @@ extern "C" int rtx_apparent_radiance(const double* X, int64_t nX, const float* e
   hipStream_t st = (hipStream_t)stream;
   const bool aligned16 = (nE % 4 == 0) && (((uintptr_t)emis | (uintptr_t)L | (uintptr_t)Ls) % 16 == 0);
   if (nA == 1 && nT == 1 && dT == nullptr && aligned16) {
-    const long long blocks = nX < 256 * 32 ? nX : 256 * 32;
+    const long long rows4 = (nX + 3) / 4;
+    const long long blocks = rows4 < 256 * 32 ? rows4 : 256 * 32;
     hipLaunchKernelGGL(apparent_radiance_row_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     RTX_LAUNCH_CHECK();
     return 0;
@@ -650,22 +659,42 @@ __global__ __launch_bounds__(256) void interp_knots_kernel(InterpArgs a) {
       s_t[threadIdx.x] = (float)t;
     }
     __syncthreads();
-    for (int r = 0; r < rows; ++r) {
-      const float tf = s_t[r];
-      const float* f0 = a.F + s_j[r] * a.nS;
-      const float* f1 = f0 + a.nS;
-      float* o = a.out + (i0 + r) * a.nS;
-      if (vec) {
-        const float4 *f04 = reinterpret_cast<const float4*>(f0), *f14 = reinterpret_cast<const float4*>(f1);
-        float4* o4 = reinterpret_cast<float4*>(o);
-        for (long long q = threadIdx.x; q < (a.nS >> 2); q += blockDim.x) {
-          const float4 u = f04[q], v = f14[q];
-          float4 w;
-          w.x = fmaf(tf, v.x - u.x, u.x); w.y = fmaf(tf, v.y - u.y, u.y);
-          w.z = fmaf(tf, v.z - u.z, u.z); w.w = fmaf(tf, v.w - u.w, u.w);
-          o4[q] = w;
+    if (vec) {
+      // a row per wave-iteration, four 16-B knot-row pairs per lane in flight before the first store
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const long long nS4 = a.nS >> 2;
+      for (int r = wave; r < rows; r += 4) {
+        const float tf = s_t[r];
+        const float4* f04 = reinterpret_cast<const float4*>(a.F + s_j[r] * a.nS);
+        const float4* f14 = reinterpret_cast<const float4*>(a.F + (s_j[r] + 1) * a.nS);
+        float4* o4 = reinterpret_cast<float4*>(a.out + (i0 + r) * a.nS);
+        for (long long q0 = 0; q0 < nS4; q0 += 256) {
+          float4 u[4], v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const long long q = q0 + lane + 64 * t;
+            const bool in = q < nS4;
+            u[t] = in ? f04[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[t] = in ? f14[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const long long q = q0 + lane + 64 * t;
+            if (q < nS4) {
+              float4 w;
+              w.x = fmaf(tf, v[t].x - u[t].x, u[t].x); w.y = fmaf(tf, v[t].y - u[t].y, u[t].y);
+              w.z = fmaf(tf, v[t].z - u[t].z, u[t].z); w.w = fmaf(tf, v[t].w - u[t].w, u[t].w);
+              o4[q] = w;
+            }
+          }
         }
-      } else {
+      }
+    } else {
+      for (int r = 0; r < rows; ++r) {
+        const float tf = s_t[r];
+        const float* f0 = a.F + s_j[r] * a.nS;
+        const float* f1 = f0 + a.nS;
+        float* o = a.out + (i0 + r) * a.nS;
         for (long long sidx = threadIdx.x; sidx < a.nS; sidx += blockDim.x) o[sidx] = fmaf(tf, f1[sidx] - f0[sidx], f0[sidx]);
       }
     }
