@@ -1,5 +1,10 @@
 // smooth / reduceResolution (radiative_transfer.py:1266-1350): the post-processing step right after compute_TUD in
 // the reference's main caller (Generate_LWIR_TUD.py:82-85,124-126). Two streaming kernels, fp64 like the reference.
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
 #include "rtx_common.h"
 
 #define FIR_MAX_TAPS 8192
@@ -38,16 +43,24 @@ __global__ __launch_bounds__(FIR_BLOCK) void fir_reflect_kernel(const T* __restr
     }
     for (int s = threadIdx.x; s < kc; s += FIR_BLOCK) s_t[s] = taps[k0 + s];
     __syncthreads();
-    double w[FIR_PER_THREAD];
+    // FIR_PER_THREAD taps at a time: the 2 FIR_PER_THREAD - 1 samples they touch are read once into registers and every
+    // (tap, output) pair indexes them statically -- no register window to shift per tap
+    int k = 0;
+    for (; k + FIR_PER_THREAD <= kc; k += FIR_PER_THREAD) {
+      double w[2 * FIR_PER_THREAD - 1], tk[FIR_PER_THREAD];
 #pragma unroll
-    for (int j = 0; j < FIR_PER_THREAD - 1; ++j) w[j + 1] = s_x[t0 + j];
-    for (int k = 0; k < kc; ++k) {
+      for (int j = 0; j < 2 * FIR_PER_THREAD - 1; ++j) w[j] = s_x[t0 + k + j];
 #pragma unroll
-      for (int j = 0; j < FIR_PER_THREAD - 1; ++j) w[j] = w[j + 1];
-      w[FIR_PER_THREAD - 1] = s_x[t0 + k + FIR_PER_THREAD - 1];
+      for (int u = 0; u < FIR_PER_THREAD; ++u) tk[u] = s_t[k + u];
+#pragma unroll
+      for (int u = 0; u < FIR_PER_THREAD; ++u)
+#pragma unroll
+        for (int j = 0; j < FIR_PER_THREAD; ++j) acc[j] = fma(tk[u], w[u + j], acc[j]);
+    }
+    for (; k < kc; ++k) {
       const double tk = s_t[k];
 #pragma unroll
-      for (int j = 0; j < FIR_PER_THREAD; ++j) acc[j] = fma(tk, w[j], acc[j]);
+      for (int j = 0; j < FIR_PER_THREAD; ++j) acc[j] = fma(tk, s_x[t0 + k + j], acc[j]);
     }
   }
 #pragma unroll
@@ -67,10 +80,32 @@ extern "C" int rtx_fir_reflect(const void* in, int in_is_f64, int64_t ld_in, int
   if (ld_in < n || ld_out < n) RTX_FAIL("leading dimension smaller than the row");
   if (n_rows > 65535) RTX_FAIL("n_rows=%d too large", n_rows);
   hipStream_t st = (hipStream_t)stream;
+  // device copies of the windows seen so far (a caller smooths every spectrum of a run with the same one or two windows):
+  // a hit costs a memcmp; only a new window is uploaded (synchronously: taps_h may be a temporary of the caller)
   double* d_taps = nullptr;
-  RTX_HIP(hipMallocAsync((void**)&d_taps, (size_t)n_taps * sizeof(double), st));
-  RTX_HIP(hipMemcpyAsync(d_taps, taps_h, (size_t)n_taps * sizeof(double), hipMemcpyHostToDevice, st));
-  RTX_HIP(hipStreamSynchronize(st));  // taps_h may be a temporary of the caller
+  {
+    struct Win { int dev; std::vector<double> h; double* d; };
+    static std::mutex mu;
+    static std::vector<Win> cache;
+    int dev = 0;
+    RTX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Win& w : cache)
+      if (w.dev == dev && (int)w.h.size() == n_taps && memcmp(w.h.data(), taps_h, (size_t)n_taps * sizeof(double)) == 0) { d_taps = w.d; break; }
+    if (!d_taps) {
+      if (cache.size() >= 64) {  // bounded: forget the oldest
+        (void)hipFree(cache.front().d);
+        cache.erase(cache.begin());
+      }
+      Win w;
+      w.dev = dev;
+      w.h.assign(taps_h, taps_h + n_taps);
+      RTX_HIP(hipMalloc((void**)&w.d, (size_t)n_taps * sizeof(double)));
+      RTX_HIP(hipMemcpy(w.d, taps_h, (size_t)n_taps * sizeof(double), hipMemcpyHostToDevice));
+      d_taps = w.d;
+      cache.push_back(std::move(w));
+    }
+  }
   const dim3 grid((unsigned)((n + FIR_TILE - 1) / FIR_TILE), (unsigned)n_rows);
   if (in_is_f64)
     hipLaunchKernelGGL(fir_reflect_kernel<double>, grid, dim3(FIR_BLOCK), 0, st, (const double*)in, (long long)ld_in, (long long)n, d_taps,
@@ -79,7 +114,6 @@ extern "C" int rtx_fir_reflect(const void* in, int in_is_f64, int64_t ld_in, int
     hipLaunchKernelGGL(fir_reflect_kernel<float>, grid, dim3(FIR_BLOCK), 0, st, (const float*)in, (long long)ld_in, (long long)n, d_taps,
                        n_taps, centre, out, (long long)ld_out);
   RTX_LAUNCH_CHECK();
-  RTX_HIP(hipFreeAsync(d_taps, st));
   return 0;
 }
 
