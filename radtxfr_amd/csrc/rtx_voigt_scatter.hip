@@ -401,8 +401,17 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #ifndef SC_NW
 #define SC_NW 2  // waves per workgroup of the nodal kernel (each takes every SC_NW-th candidate and owns a copy of the tile). 4 -> 2: the row-level groups of 8 member lines fill better when a wave sees twice the candidates (2.10 -> 2.02 ms); 1: the same as 2
 #endif
+#ifndef SC_EDGE_LIST
+#define SC_EDGE_LIST 1  // 1: lines that need nothing but ONE window-edge row in this tile (60 % of the point-by-point entries) go to a list of their own: 32-byte entries (two LDS reads and one v_readfirstlane instead of four each, no row-mask loops), 1.96 -> 1.87 ms. Entries per iteration 1 / 2 / 3 / 4: 1.90 / 1.87 / 1.89 / 1.91; capacities edge / general 48/8, 24/20, 16/24: 1.93 / 1.89 / 1.90
+#endif
+#ifndef SC_EDGE_CAP
+#define SC_EDGE_CAP 32
+#endif
+#ifndef SC_EDGE_UNROLL
+#define SC_EDGE_UNROLL 2
+#endif
 #ifndef SC_ENT_CAP
-#define SC_ENT_CAP 32  // point-by-point entries per wave (64 B each). With two waves per workgroup: 16 -> 2.02 ms, 24 -> 1.99, 32 -> 1.96, 48 -> 2.03
+#define SC_ENT_CAP (SC_EDGE_LIST ? 16 : 32)  // point-by-point entries per wave (64 B each). Without the edge list, two waves per workgroup: 16 -> 2.02 ms, 24 -> 1.99, 32 -> 1.96, 48 -> 2.03
 #endif
 // SMALLY: the instantiation for layers that hold Doppler-dominated (y < 1) lines: their band lanes take the fp64 Weideman
 // value right here (band_row MODE 2) instead of in a second pass over the layer.
@@ -412,6 +421,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const i
   constexpr int TILE = 64 * ROWS;
   __shared__ float s_acc[SC_NW][TILE];              // one private tile per wave (near rows)
   __shared__ float4 s_ent[SC_NW][SC_ENT_CAP][4];
+  __shared__ float4 s_edge[SC_NW][SC_EDGE_LIST ? SC_EDGE_CAP : 1][2];
   __shared__ float s_nodsum[RTX_SC_ROWS][CHEB_N];
   // after the last drain the entry lists are dead: wave w keeps its row-level sums [ROWS][8] in its list
   static_assert(RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "row sums fit in one wave's entry list");
@@ -498,6 +508,44 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const i
     n_ent = 0;
   };
 
+  // Window-edge entries: [a c b1 b0] [Ay Ay0 u(lane 0 of the row) packed], packed = first inside lane (left edge) or first
+  // outside lane (right edge) | row << 7 | right << 12. SC_EDGE_UNROLL entries per iteration: their reads and evaluations are
+  // independent, only the two read-add-writes of the tile copy are ordered (a wave's LDS operations complete in order, so
+  // two entries of the same row add up correctly); the list order, hence the summation order, is fixed.
+  int n_edge = 0;  // wave-uniform
+  float4(*__restrict__ edg)[2] = s_edge[wave];
+  auto edge_one = [&](const float4& E0, const float4& E1, int pk) {
+    const int r = (pk >> 7) & 31, t = pk & 127;
+    const bool right = (pk >> 12) & 1;
+    float* p = acc + r * 64 + lane;
+    const float u = E1.z + lanef;
+    const float x = fmaf(u, E0.x, E0.y);
+    const float xx = x * x;
+    float num = fmaf(xx, E1.x, E1.y);
+    const float rden = __builtin_amdgcn_rcpf(fmaf(xx + E0.z, xx, E0.w));
+    const bool inside = (lane >= t) != right;
+    num = inside ? num : 0.f;
+    p[0] = fmaf(num, rden, p[0]);
+  };
+  auto drain_edges = [&]() {
+    for (int e = 0; e < n_edge; e += SC_EDGE_UNROLL) {
+      float4 E0[SC_EDGE_UNROLL], E1[SC_EDGE_UNROLL];
+      int pk[SC_EDGE_UNROLL];
+#pragma unroll
+      for (int q = 0; q < SC_EDGE_UNROLL; ++q) {
+        const int eq = e + q < n_edge ? e + q : e;
+        E0[q] = edg[eq][0];
+        E1[q] = edg[eq][1];
+      }
+#pragma unroll
+      for (int q = 0; q < SC_EDGE_UNROLL; ++q) pk[q] = __builtin_amdgcn_readfirstlane(__float_as_int(E1[q].w));
+#pragma unroll
+      for (int q = 0; q < SC_EDGE_UNROLL; ++q)
+        if (e + q < n_edge) edge_one(E0[q], E1[q], pk[q]);
+    }
+    n_edge = 0;
+  };
+
   // 64 SC_NW candidates per round: wave w, lane i takes candidate rng.x + w + SC_NW i (+ 64 SC_NW per round)
   for (int base = rng.x + wave; base < rng.y; base += 64 * SC_NW) {
     const int slot = base + SC_NW * lane;
@@ -526,8 +574,35 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const i
     STAMP(0);  // record loads + geometry
 
     // ---- point-by-point rows: 64-byte entries, drained by the whole wave ---------------------------------------
+    bool edge_only = false;
+    if (SC_EDGE_LIST) {
+      // nothing but one window-edge row, cut on one side only
+      const bool single = m_pp == 0u && m_bd == 0u && m_ed != 0u && (m_ed & (m_ed - 1u)) == 0u;
+      const int re = single ? __builtin_ctz(m_ed) : 0;
+      const bool left = g.part_l && re == g.r_lo, rightc = g.part_r && re == g.r_hi - 1;
+      edge_only = single && (left != rightc) && !(RTX_SC_ABLATE & 8);
+      const int dlo = qlo - ia, dhi = qhi - ia;
+      const int t = left ? dlo - 64 * re : dhi - 64 * re;  // in [1, 63] for a cut row
+      const int pk = (t & 127) | (re << 7) | (left ? 0 : 1 << 12);
+      bool emit = edge_only;
+      unsigned long long eb = __ballot(emit);
+      while (eb) {
+        const int room = SC_EDGE_CAP - n_edge;
+        const int r = __popcll(eb & lt);
+        if (emit && r < room) {
+          float4* d = edg[n_edge + r];
+          d[0] = f0;
+          d[1] = make_float4(f1.x, f1.y, ub + (float)(64 * re), __int_as_float(pk));
+          emit = false;
+        }
+        const int cnt = __popcll(eb);
+        n_edge += cnt < room ? cnt : room;
+        if (n_edge == SC_EDGE_CAP) drain_edges();
+        eb = __ballot(emit);
+      }
+    }
     {
-      bool emit = !(RTX_SC_ABLATE & 8) && (m_pp | m_ed | m_bd) != 0u;
+      bool emit = !(RTX_SC_ABLATE & 8) && !edge_only && (m_pp | m_ed | m_bd) != 0u;
       unsigned long long eb = __ballot(emit);
       while (eb) {
         const int room = SC_ENT_CAP - n_ent;
@@ -603,6 +678,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const i
     STAMP(2);  // row level
   }
   drain();
+  if (SC_EDGE_LIST) drain_edges();
 
   // sum the 8 member slots of each node (lanes l = 0..7 of equal j), one copy per wave
 #pragma unroll
