@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-dom = sys.argv[2] if len(sys.argv) > 2 else "voigt_nodal_kernel"
+dom = sys.argv[2] if len(sys.argv) > 2 else "voigt_nodal_kernel<false>"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
