@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #define SC_NW 2  // waves per workgroup of the nodal kernel (each takes every SC_NW-th candidate and owns a copy of the tile). 4 -> 2: the row-level groups of 8 member lines fill better when a wave sees twice the candidates (2.10 -> 2.02 ms); 1: the same as 2
 #endif
 #ifndef SC_EDGE_LIST
-#define SC_EDGE_LIST 1  // 1: lines that need nothing but ONE window-edge row in this tile (60 % of the point-by-point entries) go to a list of their own: 32-byte entries (two LDS reads and one v_readfirstlane instead of four each, no row-mask loops), 1.96 -> 1.87 ms. Entries per iteration 1 / 2 / 3 / 4: 1.90 / 1.87 / 1.89 / 1.91; capacities edge / general 48/8, 24/20, 16/24: 1.93 / 1.89 / 1.90
+#define SC_EDGE_LIST 1  // 1: lines that need nothing but ONE window-edge row in this tile (60 % of the point-by-point entries) go to a list of their own: 32-byte entries (two LDS reads and one v_readfirstlane instead of four each, no row-mask loops), 1.96 -> 1.87 ms. Entries per iteration 1 / 2 / 3 / 4: 1.90 / 1.87 / 1.89 / 1.91; capacities edge / general 48/8, 24/20, 16/24: 1.93 / 1.89 / 1.90; the near-zone-only lines (a run of whole rows, no band) through the same list with a row loop: no change (1.90 / 1.90)
 #endif
 #ifndef SC_EDGE_CAP
 #define SC_EDGE_CAP 32
