@@ -319,13 +319,16 @@ def main():
                        "line_table": "synthetic HITRAN-format H2O+CO2, seed 20261005",
                        "parallelism": f"wavenumber-sharded x{world}" + (" + 1 RCCL all-gather" if world > 1 else "")},
             "roofline": {"kernel": "voigt_nodal_kernel",
-                         # the kernel writes 1.09x its algorithmic bytes and is nowhere near HBM speed: what binds it is
+                         # the kernel moves 1.1x its algorithmic bytes and is nowhere near HBM speed: what binds it is
                          # vector-instruction issue (SURVEY 8d stage A). The contract's HBM figures stay in
                          # achieved/peak/frac; `valu` is the roofline it is actually up against.
                          "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": tsrc if traffic is not None else None,
                          "ms_per_launch": ms_voigt, "algorithmic_bytes_per_launch": alg_bytes,
+                         "ms_per_launch_covers": "HIP events around rtx_voigt_sum: tile_ranges_kernel + voigt_nodal_kernel<false> "
+                                                 "+ its empty <true> instantiation and the gaps between them (rocprofv3 times "
+                                                 "the nodal kernel alone: profiles/*_bench_kernel_stats.csv)",
                          "valu": valu,
                          "note": "achieved/peak/frac are the HBM roofline the contract asks for (algorithmic bytes / "
                                  "launch time / 8 TB/s); the kernel is VALU-issue-bound, see `valu` and DESIGN.md 4.2",
