@@ -211,7 +211,9 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 //   thin  : e = em_thin(y),      L <- L + e (B - L)
 //   mixed : per lane, the thin form where |y| < 1/8 and the thick form elsewhere
 // OD is read once per block of streams, coalesced along the wavenumber axis.
-#define TUD_STAGE 8
+#ifndef TUD_STAGE
+#define TUD_STAGE 4  // layers fetched ahead per chunk (tud_g_kernel, C3 column / thinned: 4 -> 0.212 / 0.296 ms, 8 -> 0.219 / 0.305, 16 -> 0.246 / 0.331)
+#endif
 #ifndef TUD_ABLATE
 #define TUD_ABLATE 0  /* timing experiments: 1 = all-thin layers skip the stream updates, 2 = no Planck evaluation, 4 = no up-path */
 #endif
