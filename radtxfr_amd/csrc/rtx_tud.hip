@@ -225,7 +225,7 @@ __device__ __forceinline__ float em_thin(float y) {  // valid for -1/8 < y <= 0
 // registers, n_layers loads in flight per wave instead of 8), and the opaque-slab scan, the further (altitude, slant)
 // pairs and the main pass all read OD from LDS -- HBM is read exactly once. Up to TUD_COL_LAYERS layers (36 KB per
 // workgroup, 4 workgroups per CU); deeper columns (the reference's default 66-layer table) take the chunked form
-// (COL = false: 8 layers at a time through registers, scan by batched global loads).
+// (COL = false: TUD_STAGE layers at a time through registers, scan by batched global loads).
 #define TUD_COL_LAYERS 36
 template <int NA, bool COL>
 __global__ __launch_bounds__(256) void tud_kernel(TudArgs a) {
