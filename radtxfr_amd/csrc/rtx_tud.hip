@@ -3,12 +3,16 @@
 // rtx_planck : planckian(), reference radiative_transfer.py:792-848, fp64 like the reference.
 // rtx_tud    : body of compute_TUD after the OD loop, radiative_transfer.py:340-392.
 //
-// TUD mapping (CDNA4): lane <-> wavenumber (coalesced dword loads of the layer-major OD), one point
-// per lane; the lane keeps its NL optical depths and NL Planck values in VGPRs (the layer loops are
-// fully unrolled so the arrays never touch scratch) and runs the nL-step recurrences for every
-// slant angle out of registers: OD is read from HBM exactly once, B is never materialised
-// (the reference builds an (nX,nL) fp64 temporary, :340). The binding resource is the
-// transcendental pipe: (1 + N_angle) exp per wavenumber-layer point (stage B).
+// TUD mapping (CDNA4): lane <-> wavenumber (coalesced dword loads of the layer-major OD), one point per lane, a
+// run-time loop over the layers; OD is read from HBM exactly once and B is never materialised (the reference builds
+// an (nX,nL) fp64 temporary, :340). Kernels, in the order the dispatcher prefers them:
+//   tud_g_kernel        one (altitude, slant) pair: tau, L-up (bottom-up recurrence) and the downwelling as
+//                       sum_k B_k [G(S_k) - G(S_k+1)], G = the angle-summed transmission function, tabulated in fp64
+//   tud_g_snap_kernel   several altitudes / slants on an ascending height grid: one recurrence per slant, an altitude's
+//                       outputs stored when the pass has done its count of layers
+//   tud_g_pairs_kernel  the same for masks that are not prefixes: pairs in blocks of 3
+//   tud_kernel<NA,COL>  the N_angle stream recurrences in registers (round 1's kernel): per-stream radiances
+//                       (opts['save']) and the cross-check RADTXFR_TUD_KERNEL=streams
 //
 // Precision: exp arguments of the Planck term reach c2*nu/T ~ 40, where an fp32 argument alone
 // costs 2.4e-6; the argument is formed in fp64, split into integer and fractional powers of two,
@@ -17,6 +21,10 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "rtx_common.h"
 
@@ -986,9 +994,6 @@ __global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
 }
 
 // Host side of G: piecewise Chebyshev interpolants of degree TUDG_DEG in fp64, stored as monomials in (S - mid).
-#include <map>
-#include <mutex>
-#include <vector>
 struct GTab { double* dev; double g0; };
 static int tudg_table(int n_angle, GTab* out) {
   static std::mutex mu;
