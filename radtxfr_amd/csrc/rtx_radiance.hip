@@ -8,7 +8,8 @@
 // almost nothing, so one workgroup owns one spectral channel, stages B(X, Ts+dT) for that channel
 // in LDS (fp64 Planck, once per (a,t)) and streams the [nE][nA][nT] slab with coalesced stores.
 // The ILS never builds the reference's dense (nS,nX,nB) temporary: each band only visits the grid
-// points under its own weight function.
+// points under its own weight function; on a large materialised Y it runs in one pass over the rows
+// (ils_rows_kernel: every row is fetched once although ~3 triangles or ~15 Gaussians cover it).
 #include <map>
 #include <mutex>
 #include <stdlib.h>
