@@ -162,6 +162,12 @@ int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_layers, con
             int n_alt, const uint8_t* mask_h, int n_mu, const double* mu_h, int n_down,
             int n_angle, int return_od, float* tau, float* Lu, float* Ld, float* Ld_angles,
             int64_t ld_out, void* stream);
+/* The tabulated G of rtx_tud, for host-side checks (no device involved): rtx_tud_gtable_size() doubles, rows of
+ * {interval centre, a0 .. a6}: G(S) = sum a_k (S - centre)^k on the row's interval; intervals: 16 per binade of
+ * S + 2^-6 below S = 16 (row = (bits(float(S) + 2^-6) >> 19) - (bits(2^-6) >> 19)), width 1/2 from there to S = 48.
+ * g0_h receives G(0) = the sum of the quadrature weights cos(theta) sin(theta) (radiative_transfer.py:387). */
+int rtx_tud_gtable_size(void);
+int rtx_tud_gtable(int n_angle, double* table_h, double* g0_h);
 
 /* compute_TUD in ONE call: radiative_transfer.py:274-392 with compute_OD (:395-456, the LBLRTM run) replaced by the
  * Voigt line-sum -- rtx_line_prep (profile Voigt, scale 1) + rtx_voigt_sum into OD[n_layers][ld_od] + rtx_tud, enqueued

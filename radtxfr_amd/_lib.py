@@ -41,6 +41,8 @@ PROTOTYPES = {
     "rtx_voigt_tile_points": (_i32, []),
     "rtx_planck": (_i32, [_gp, _vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "rtx_tud": (_i32, [_vp, _i64, _gp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "rtx_tud_gtable_size": (_i32, []),
+    "rtx_tud_gtable": (_i32, [_i32, _vp, _vp]),
     "rtx_compute_tud": (_i32, [_vp, _vp, _gp, _i32, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _vp, _i32, _vp,
                                 _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "rtx_apparent_radiance": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -995,14 +995,7 @@ __global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
 
 // Host side of G: piecewise Chebyshev interpolants of degree TUDG_DEG in fp64, stored as monomials in (S - mid).
 struct GTab { double* dev; double g0; };
-static int tudg_table(int n_angle, GTab* out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, int>, GTab> cache;  // (device, n_angle)
-  int dev = 0;
-  RTX_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find({dev, n_angle});
-  if (it != cache.end()) { *out = it->second; return 0; }
+static void tudg_build(int n_angle, std::vector<double>& tab, double& g0_out) {
   std::vector<double> w, sec;
   const double dth = (M_PI / 2.0) / (double)n_angle;
   double g0 = 0.0;
@@ -1014,7 +1007,7 @@ static int tudg_table(int n_angle, GTab* out) {
   }
   auto G = [&](double S) { double r = 0.0; for (size_t q = 0; q < w.size(); ++q) r += w[q] * exp(-S * sec[q]); return r; };
   constexpr int N = TUDG_DEG + 1;
-  std::vector<double> tab((size_t)TUDG_NINT * 8, 0.0);
+  tab.assign((size_t)TUDG_NINT * 8, 0.0);
   for (int idx = 0; idx < TUDG_NINT; ++idx) {
     double lo, hi;
     if (idx < TUDG_NLOG) {
@@ -1052,8 +1045,32 @@ static int tudg_table(int n_angle, GTab* out) {
     double sc = 1.0;
     for (int d = 0; d < N; ++d) { row[1 + d] = mono[d] * sc; sc /= hw; }
   }
+  g0_out = g0;
+}
+
+// The table as the kernels see it, for host-side checks (tests/test_host.py evaluates it in NumPy against the direct sum;
+// no device involved): table_h [rtx_tud_gtable_size()] doubles = TUDG_NINT rows of {interval centre, a0 .. a6}.
+extern "C" int rtx_tud_gtable_size(void) { return TUDG_NINT * 8; }
+extern "C" int rtx_tud_gtable(int n_angle, double* table_h, double* g0_h) {
+  if (n_angle < 1 || n_angle > TUD_MAX_ANGLES - 32) RTX_FAIL("n_angle=%d outside [1,%d]", n_angle, TUD_MAX_ANGLES - 32);
+  if (!table_h || !g0_h) RTX_FAIL("a required pointer is NULL");
+  std::vector<double> tab;
+  tudg_build(n_angle, tab, *g0_h);
+  memcpy(table_h, tab.data(), tab.size() * sizeof(double));
+  return 0;
+}
+
+static int tudg_table(int n_angle, GTab* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, GTab> cache;  // (device, n_angle)
+  int dev = 0;
+  RTX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find({dev, n_angle});
+  if (it != cache.end()) { *out = it->second; return 0; }
+  std::vector<double> tab;
   GTab t;
-  t.g0 = g0;
+  tudg_build(n_angle, tab, t.g0);
   RTX_HIP(hipMalloc(&t.dev, tab.size() * sizeof(double)));
   RTX_HIP(hipMemcpy(t.dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   cache[{dev, n_angle}] = t;

@@ -359,3 +359,42 @@ def test_reference_module_surface_is_complete():
     for name in ("write_tape5", "run_LBLRTM", "read_tape12"):
         with pytest.raises(NotImplementedError):
             getattr(rt, name)()
+
+
+def test_tud_downwelling_table_against_direct_sum():
+    """The angle-summed transmission function G(S) = sum_q w_q exp(-S / cos theta_q) that rtx_tud tabulates (piecewise
+    degree-6 polynomials), rebuilt here from the table the library hands out and the index rule its header
+    states, against the direct sum over the reference's quadrature (radiative_transfer.py:368, 387): <= 1e-13 G(0) in absolute
+    terms everywhere on [0, 48], <= 1e-9 relative where G has dropped by orders of magnitude. Host code only: no GPU."""
+    import ctypes as C
+    from radtxfr_amd import _lib
+    lib = _lib.load()
+    n = lib.rtx_tud_gtable_size()
+    assert n % 8 == 0
+    rng = np.random.default_rng(20261014)
+    S = np.concatenate([rng.uniform(0, 1, 50000) ** 4, rng.uniform(0, 16, 50000), rng.uniform(16, 48, 20000), 10.0 ** rng.uniform(-12, -3, 20000),
+                        [0.0, 1.0 / 64 - 1e-12, 1.0 / 64, 16.0 - 1e-9, 16.0, 47.999999]])
+    for n_angle in (2, 3, 30, 96):
+        tab = np.zeros(n)
+        g0 = C.c_double(0.0)
+        assert lib.rtx_tud_gtable(n_angle, tab.ctypes.data_as(C.c_void_p), C.byref(g0)) == 0
+        tab = tab.reshape(-1, 8)
+        th = np.arange(n_angle) * (np.pi / 2 / n_angle)   # np.linspace(0, pi/2, n, endpoint=False)
+        w, sec = np.cos(th) * np.sin(th), 1.0 / np.cos(th)
+        assert abs(g0.value - w.sum()) <= 1e-14 * w.sum()
+        direct = (w[None, 1:] * np.exp(-S[:, None] * sec[None, 1:])).sum(1)
+        # the kernel's index: float bits of (float(S) + 2^-6) below 16, half-unit intervals above
+        sf = S.astype(np.float32)
+        bits = (sf + np.float32(2.0 ** -6)).view(np.int32).astype(np.int64)
+        base = int(np.float32(2.0 ** -6).view(np.int32)) >> 19
+        n_log = (int(np.float32(16.0).view(np.int32)) >> 19) - base + 1
+        idx = np.where(sf < 16.0, (bits >> 19) - base, n_log + ((sf - np.float32(16.0)) * np.float32(2.0)).astype(np.int64))
+        idx = np.clip(idx, 0, tab.shape[0] - 1)
+        u = S - tab[idx, 0]
+        val = tab[idx, 7]
+        for k in range(6, 0, -1):
+            val = val * u + tab[idx, k]
+        err = np.abs(val - direct)
+        assert err.max() <= 1e-13 * g0.value, (n_angle, err.max())
+        far = (direct < 1e-4 * g0.value) & (direct > 1e-14 * g0.value)   # below that nothing reaches fp32 output
+        assert np.max(err[far] / direct[far]) <= 2e-8, (n_angle, np.max(err[far] / direct[far]))
