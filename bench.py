@@ -18,8 +18,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with these extr
                   counts), and the other kernels' times, including the TUD kernel on an optically thin column
   cpu_baseline -- the NumPy oracle (port of the reference's CPU path) on a bounded sample: one core, and a process pool
                   over wavenumber chunks (the reference's multiprocessing.Pool pattern, Generate_LWIR_TUD.py:138-143)
-  checksum     -- sums of the final tau / L-up / L-down (N > 1: of the all-gathered block), so runs at different N
-                  can be compared
+  checksum     -- sums of the final tau / L-up / L-down (N > 1: of the all-gathered block). Shards are cut on line-sum
+                  tile boundaries (dist.tile_aligned_bounds), so the spectra -- and these sums -- are IDENTICAL for every N
+  sharding     -- (N > 1) per-rank shard lengths and line counts, per-rank kernel time of one step (min / max / all ranks:
+                  the balance across ranks), `collective_ms` = one un-overlapped all-gather, `bytes_gathered`
 """
 import argparse
 import json
@@ -40,7 +42,9 @@ CYC_VALU, CYC_TRANS = 2.0, 8.0  # issue cycles per wave64 VALU instruction / per
 N_WAVENUMBERS = 5500000
 N_LINES = 100000
 N_LAYERS = 32
-POOL_MAX = 16          # a one-GPU box grants ~16 host cores (of 256 visible)
+POOL_MAX = 16          # pool size of the CPU baseline. A one-GPU box lists 256 usable CPUs but its share is 16: measured on
+                       # it (gpurun_out/r3/bench_1.json), 64 workers give 6.4e6 points/s in 1417 CPU-seconds -- each worker
+                       # four times slower than the single-core leg -- against 6.8e6 with 16 workers
 
 
 def _cpu_chunk(job):
@@ -76,20 +80,29 @@ def cpu_baseline():
     cores = max(1, min(avail, POOL_MAX))
     nchunk, n2 = 2 * cores, 40000
     starts = np.linspace(0, N_WAVENUMBERS - n2, nchunk).astype(np.int64)
-    t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
+        t0 = time.perf_counter()
+        pool.map(_cpu_warm, range(cores), chunksize=1)  # interpreter start-up + imports of every worker: outside the timed wall
+        t_start = time.perf_counter() - t0
+        t0 = time.perf_counter()
         res = pool.map(_cpu_chunk, [(int(s), n2) for s in starts], chunksize=1)
-    wall = time.perf_counter() - t0
+        wall = time.perf_counter() - t0
     pooled = nchunk * n2 * N_LAYERS / wall
     return {"value": pooled, "unit": "wavenumber*layer points/s", "cores": cores, "kind": "port",
             "sample": f"{nchunk} chunks of {n2} wavenumbers spread over 500-6000 cm^-1 x {N_LAYERS} layers "
                       f"({nchunk * n2} of {N_WAVENUMBERS}), NumPy fp64 oracle, multiprocessing pool of {cores} "
-                      f"(Generate_LWIR_TUD.py:138-143 pattern), {wall:.1f} s wall incl. worker start-up, "
+                      f"(Generate_LWIR_TUD.py:138-143 pattern), {wall:.1f} s wall (worker start-up {t_start:.1f} s excluded), "
                       f"{sum(r[0] for r in res):.1f} s CPU",
             "single_core": {"value": single, "cores": 1,
                             "sample": f"{n1} of {N_WAVENUMBERS} wavenumbers (3000.0-3160.0 cm^-1) x {N_LAYERS} layers, "
                                       f"{nl1} lines in reach, {dt1:.1f} s"},
             "host_cpus": os.cpu_count(), "usable_cpus": avail}
+
+
+def _cpu_warm(_):
+    from oracle import cpu_ref  # noqa: F401
+    from radtxfr_amd import synthetic  # noqa: F401
+    return 0
 
 
 def _latest_profile(suffix):
@@ -138,15 +151,17 @@ def main():
     full = synthetic.synth_line_table(synthetic.SEED_C3, N_LINES, 475.0, 6025.0)
     atm = synthetic.c3_atmosphere(N_LAYERS)
     grid_full = engine.Grid(500.0, 6000.0, N_WAVENUMBERS)
-    per = (N_WAVENUMBERS + world - 1) // world
-    off = min(rank * per, N_WAVENUMBERS)
-    n_loc = max(0, min(per, N_WAVENUMBERS - off))
+    # tile-aligned shards weighted by the per-tile cost estimate (dist.tud_shard_plan): every N computes the same bits,
+    # and no rank is left with the expensive high-wavenumber end. `per` = the longest shard = the all-gather block.
+    from radtxfr_amd import dist as rdist
+    offs, reach = rdist.tud_shard_plan(full, 500.0, 6000.0, N_WAVENUMBERS, atm["Ts"], atm["Ps"], world)
+    off, n_loc = int(offs[rank]), int(offs[rank + 1] - offs[rank])
+    per = int(np.diff(offs).max())
     grid = grid_full.shard(off, n_loc)
     # each rank only needs the lines whose wings can reach its shard
     if world > 1:
-        reach = engine.max_wing_cm(full, atm["Ts"], atm["Ps"] / 101325.0) + 1.0
-        xs = grid.axis()
-        table = synthetic.subset_table(full, xs[0] - reach, xs[-1] + reach)
+        xs = (grid.x_at(0), grid.x_at(max(n_loc, 1) - 1))
+        table = synthetic.subset_table(full, xs[0] - reach, xs[1] + reach)
     else:
         table = full
     lines = engine.LineTable(table)
@@ -221,43 +236,107 @@ def main():
         dt = float(tt.item())
 
     # ---- checksum of the final spectra (N > 1: the all-gathered block, as every rank holds it) ----------------
+    # formed the same way for every N -- one contiguous [3][nX] block -- so equal spectra give equal sums; `bits` adds the
+    # float32 bit patterns as integers (exact, order-independent): equal iff the spectra are bit-identical
     if world > 1:
-        g = gathered[last["b"]].view(world, 3, per).permute(1, 0, 2).reshape(3, world * per)[:, :N_WAVENUMBERS].double()
-        sums = [float(g[c].sum()) for c in range(3)]
+        g3 = gathered[last["b"]].view(world, 3, per)
+        g = torch.cat([g3[r, :, :int(offs[r + 1] - offs[r])] for r in range(world)], dim=1).contiguous()
     else:
-        sums = [float(v.double().sum()) for v in last["out"]]
+        g = torch.stack([last["out"][0][0], last["out"][1][0], last["out"][2]]).contiguous()
+    assert g.shape == (3, N_WAVENUMBERS) and g.dtype == torch.float32
+    sums = [float(g[c].double().sum()) for c in range(3)]
+    bits = [int(g[c].view(torch.int32).to(torch.int64).sum().item()) for c in range(3)]
+
+    # ---- N > 1: the balance across ranks and the collective, each measured on its own (outside `value`) ---------
+    sharding = None
+    if world > 1:
+        NB = 4
+        t_k = []
+        for _ in range(3):  # NB steps back to back, no gather in between: this rank's kernels alone
+            if runner is None:
+                t_k.append(0.0)
+                continue
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(NB):
+                runner.run(T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
+            ev[1].record()
+            torch.cuda.synchronize()
+            t_k.append(ev[0].elapsed_time(ev[1]) / NB)
+        cdev = dev if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([float(np.median(t_k)), float(n_loc), float(lines.n)], dtype=torch.float64, device=cdev)
+        allr = torch.empty((world, 3), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr.view(-1), mine)
+        allr = allr.cpu().numpy()
+        t_c = []
+        for _ in range(5):  # one all-gather with nothing else in flight, bracketed by barriers
+            dist.barrier()
+            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                ev[0].record()
+                dist.all_gather_into_tensor(gathered[0], packed[0].view(-1))
+                ev[1].record()
+                torch.cuda.synchronize()
+                t_c.append(ev[0].elapsed_time(ev[1]))
+            else:
+                tc0 = time.perf_counter()
+                g_cpu = torch.empty(gathered[0].shape, dtype=gathered[0].dtype)
+                dist.all_gather_into_tensor(g_cpu, packed[0].view(-1).cpu())
+                gathered[0].copy_(g_cpu)
+                torch.cuda.synchronize()
+                t_c.append((time.perf_counter() - tc0) * 1e3)
+        tcoll = torch.tensor([float(np.median(t_c))], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tcoll, op=dist.ReduceOp.MAX)
+        km = allr[:, 0]
+        sharding = {"offsets": [int(v) for v in offs], "points_per_rank": [int(v) for v in allr[:, 1]],
+                    "lines_per_rank": [int(v) for v in allr[:, 2]],
+                    "kernel_ms": {"min": float(km.min()), "max": float(km.max()), "per_rank": [float(v) for v in km],
+                                  "covers": "prologue + tile ranges + line-sum + TUD of this rank's shard, %d steps back to back, HIP events" % NB},
+                    "collective_ms": float(tcoll.item()),
+                    "collective": ("one RCCL all_gather_into_tensor, un-overlapped, HIP events on the launch stream, max over ranks"
+                                   if args.backend == "nccl" else "gloo rehearsal: staged through the host, NOT a measurement"),
+                    "bytes_gathered": int(world * 3 * per * 4), "bytes_per_rank": int(3 * per * 4),
+                    "balance": "tile-aligned shards weighted by engine.tile_costs"}
 
     # ---- per-kernel launch time of the dominant kernel, HIP events on the launch stream ----------
-    # (the same kernels through the three separate entry points, so that events can sit between the stages)
+    # (the same kernels through the three separate entry points, so that events can sit between the stages; NB launches
+    # back to back per sample -- a synchronise per launch would put the launch latency inside the brackets)
+    NB = 4
     t_voigt, t_tud = [], []
+    import ctypes as C
+    plan = lines.plan(N_LAYERS, n_loc) if n_loc > 0 else None
     for _ in range(min(max(args.steps, 3), 5)):
         if n_loc == 0:
             break
         w, p_atm, qratio, mass = host_factors(atm["MFs_VAL"])
+        torch.cuda.synchronize()
         ev[0].record()
-        engine.voigt_sum(lines, grid, T, p_atm, w, out_f32=OD, qratio=qratio, mass=mass)
+        for _ in range(NB):
+            engine.voigt_sum(lines, grid, T, p_atm, w, out_f32=OD, qratio=qratio, mass=mass)
         ev[1].record()
-        engine.tud(OD, grid, T, Z)
+        for _ in range(NB):
+            engine.tud(OD, grid, T, Z)
         ev[2].record()
         torch.cuda.synchronize()
-        t_voigt.append(ev[0].elapsed_time(ev[1]))  # prologue + tile ranges + line-sum kernel (+ its empty fp64 pass)
-        t_tud.append(ev[1].elapsed_time(ev[2]))
+        t_voigt.append(ev[0].elapsed_time(ev[1]) / NB)  # prologue + tile ranges + line-sum kernel (+ its empty fp64 pass)
+        t_tud.append(ev[1].elapsed_time(ev[2]) / NB)
     drain()
-    # isolate the line-sum kernel: time the prologue alone and subtract
-    import ctypes as C
-    plan = lines.plan(N_LAYERS, n_loc)
-    w, p_atm, qratio, mass = host_factors(atm["MFs_VAL"])
-    keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (T, p_atm, qratio, w, mass)]
+    # isolate the line-sum kernel: time the prologue alone, the same way, and subtract
     t_prep = []
-    for _ in range(3):
-        ev[0].record()
-        _lib.check(lib.rtx_line_prep(plan._h, lines._h, grid.byref(), N_LAYERS, *[k.ctypes.data_as(C.c_void_p) for k in keep],
-                                     1.0, 0.0, 0.0, 50.0, 0.0, 1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        ev[1].record()
-        torch.cuda.synchronize()
-        t_prep.append(ev[0].elapsed_time(ev[1]))
-    ms_voigt = float(np.median(t_voigt) - np.median(t_prep))
-    ms_tud = float(np.median(t_tud))
+    if n_loc > 0:
+        w, p_atm, qratio, mass = host_factors(atm["MFs_VAL"])
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (T, p_atm, qratio, w, mass)]
+        for _ in range(3):
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(NB):
+                _lib.check(lib.rtx_line_prep(plan._h, lines._h, grid.byref(), N_LAYERS, *[k.ctypes.data_as(C.c_void_p) for k in keep],
+                                             1.0, 0.0, 0.0, 50.0, 0.0, 1.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            ev[1].record()
+            torch.cuda.synchronize()
+            t_prep.append(ev[0].elapsed_time(ev[1]) / NB)
+    ms_voigt = float(np.median(t_voigt) - np.median(t_prep)) if t_voigt else float("nan")
+    ms_tud = float(np.median(t_tud)) if t_tud else float("nan")
     # the TUD kernel on an optically THIN column of the same grid (mixing ratios x 1e-3: tau spans (0,1) inside most
     # waves, every layer runs all 29 streams). The C3 column of SURVEY 8d is opaque almost everywhere, which lets the
     # kernel skip most streams; real LWIR atmospheres have windows. Outside `value`.
@@ -326,8 +405,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": tsrc if traffic is not None else None,
                          "ms_per_launch": ms_voigt, "algorithmic_bytes_per_launch": alg_bytes,
-                         "ms_per_launch_covers": "HIP events around rtx_voigt_sum: tile_ranges_kernel + voigt_nodal_kernel<false> "
-                                                 "+ its empty <true> instantiation and the gaps between them (rocprofv3 times "
+                         "ms_per_launch_covers": "HIP events around 4 back-to-back rtx_voigt_sum calls / 4: tile_ranges + tile_trim + "
+                                                 "voigt_nodal_kernel<false> + its empty <true> instantiation (rocprofv3 times "
                                                  "the nodal kernel alone: profiles/*_bench_kernel_stats.csv)",
                          "valu": valu,
                          "note": "achieved/peak/frac are the HBM roofline the contract asks for (algorithmic bytes / "
@@ -335,11 +414,15 @@ def main():
                          "other_kernels_ms": {"line_prep_kernel": float(np.median(t_prep)), "tud_kernel": ms_tud,
                                               "tud_kernel_thin": ms_tud_thin,
                                               "tud_kernel_thin_note": "same grid, mixing ratios x1e-3 (tau spans (0,1)); outside `value`"}},
-            "checksum": {"tau_sum": sums[0], "Lu_sum": sums[1], "Ld_sum": sums[2]},
+            "checksum": {"tau_sum": sums[0], "Lu_sum": sums[1], "Ld_sum": sums[2], "tau_bits": bits[0], "Lu_bits": bits[1],
+                         "Ld_bits": bits[2], "note": "identical for every --gpus N (tile-aligned shards): *_bits is the exact integer sum "
+                                                     "of the float32 bit patterns"},
             "device": name,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if sharding is not None:
+            out["sharding"] = sharding
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

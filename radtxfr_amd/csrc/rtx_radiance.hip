@@ -560,14 +560,17 @@ __global__ __launch_bounds__(256) void ils_rows_reduce_kernel(IlsRowsArgs r) {
   reinterpret_cast<float4*>(a.Yout + (size_t)b * a.nS)[col4] = o;
 }
 
-// grow-only workspace of the one-pass form, per device
-static int ils_rows_workspace(size_t bytes, void** out) {
+// grow-only workspace of the one-pass form, per (device, stream): two rtx_ils calls in flight on different streams (or
+// from different host threads on their own streams) must not share partial sums and the overflow flag; calls on ONE stream
+// are ordered by it. A workspace is re-allocated only to grow, and hipFree waits for the device, so a launch already
+// enqueued on that stream never loses its buffer.
+static int ils_rows_workspace(size_t bytes, hipStream_t st, void** out) {
   static std::mutex mu;
-  static std::map<int, std::pair<void*, size_t>> ws;
+  static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> ws;
   int dev = 0;
   RTX_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(mu);
-  auto& e = ws[dev];
+  auto& e = ws[std::make_pair(dev, st)];
   if (e.second < bytes) {
     if (e.first) RTX_HIP(hipFree(e.first));
     e.first = nullptr; e.second = 0;
@@ -607,7 +610,7 @@ extern "C" int rtx_ils(int kind, const rtx_grid* grid, const double* X, int64_t 
       r.a = a; r.n_chunks = (int)n_chunks; r.slots = kind == 0 ? ILS_SLOTS_TRI : ILS_SLOTS_GAUSS;
       const size_t nP = (size_t)n_chunks * r.slots * (size_t)nS, nW = (size_t)n_chunks * r.slots;
       void* base = nullptr;
-      if (ils_rows_workspace((nP + nW) * sizeof(float) + (2 * (size_t)n_chunks + 1) * sizeof(int), &base)) return 1;
+      if (ils_rows_workspace((nP + nW) * sizeof(float) + (2 * (size_t)n_chunks + 1) * sizeof(int), st, &base)) return 1;
       r.P = (float*)base; r.Wt = r.P + nP; r.b0 = (int*)(r.Wt + nW); r.overflow = r.b0 + 2 * n_chunks;
       RTX_HIP(hipMemsetAsync(r.overflow, 0, sizeof(int), st));
       if (kind == 0) hipLaunchKernelGGL((ils_rows_kernel<0, ILS_CAP>), dim3((unsigned)n_chunks, (unsigned)((nS / 4 + 63) / 64)), dim3(256), 0, st, r);

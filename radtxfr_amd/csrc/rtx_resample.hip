@@ -82,14 +82,16 @@ extern "C" int rtx_fir_reflect(const void* in, int in_is_f64, int64_t ld_in, int
   hipStream_t st = (hipStream_t)stream;
   // device copies of the windows seen so far (a caller smooths every spectrum of a run with the same one or two windows):
   // a hit costs a memcmp; only a new window is uploaded (synchronously: taps_h may be a temporary of the caller)
+  // The lock is held until the kernel that reads the taps is enqueued: an eviction by another host thread (hipFree, which
+  // waits for the device) can then only come after the launch, never between the look-up and it.
   double* d_taps = nullptr;
+  struct Win { int dev; std::vector<double> h; double* d; };
+  static std::mutex mu;
+  static std::vector<Win> cache;
+  std::lock_guard<std::mutex> lock(mu);
   {
-    struct Win { int dev; std::vector<double> h; double* d; };
-    static std::mutex mu;
-    static std::vector<Win> cache;
     int dev = 0;
     RTX_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
     for (const Win& w : cache)
       if (w.dev == dev && (int)w.h.size() == n_taps && memcmp(w.h.data(), taps_h, (size_t)n_taps * sizeof(double)) == 0) { d_taps = w.d; break; }
     if (!d_taps) {

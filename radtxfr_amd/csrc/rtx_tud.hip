@@ -1165,7 +1165,9 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
         if ((mask_h[(size_t)ia * n_layers + k] != 0) != (k < a.count[ia])) { prefix = false; break; }
     // B_k across a wave by a parabola through three of its wavenumbers (PlanckNodes) where that is exact to 1e-10:
     // |d ln B / d nu| <= 4/nu + c2/T, and the parabola's error is 0.008 (that x 63 steps)^3
-    const double nu_lo = grid->xmin + grid->step * (double)grid->offset;
+    // decided on the FULL axis (its lowest wavenumber is the worst case), so that every wavenumber shard runs the
+    // instantiation the single-rank run does; a shard offset that is a multiple of 64 then has the same waves, hence bits
+    const double nu_lo = grid->xmin;
     const bool pn = nu_lo > 0.0 && (4.0 / nu_lo + RT_C2 * 100.0 / t_min) * 63.0 * grid->step <= 7e-3;
     a.planck_nodes = pn ? 1 : 0;
     if (n_alt * n_mu == 1) {

@@ -14,6 +14,7 @@
 struct RangeArgs {
   const int* ic;
   const int* maxhw;
+  const LineRec* rec;
   long long n_lines;
   int n_tiles, tile, n_layers;
   long long n;
@@ -44,7 +45,41 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
   a.ranges[(size_t)k * a.n_tiles + t] = make_int2((int)l0, (int)lo);
 }
 
-extern "C" int rtx_voigt_scatter_tile_points(void);
+// Canonical ranges: [first line that REACHES the tile, last such line + 1). The bracket above depends on maxhw -- a maximum
+// over whatever table the caller uploaded -- and the line-sum deals candidates to waves and lanes by their position in the
+// range, so the order of its fp32 sums would depend on the bracket. Trimmed to the reaching lines, the range -- hence every
+// bit of the result -- is a function of the lines that contribute to the tile and of nothing else: a rank that holds only
+// the lines in reach of its wavenumber shard reproduces the full-table, full-grid run exactly (shards cut on tile
+// boundaries; dist.py, bench.py). One wave per (tile, layer): 64 candidates' windows per step, from each end.
+__global__ __launch_bounds__(256) void tile_trim_kernel(RangeArgs a) {
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  const int k = blockIdx.y;
+  if (wave >= a.n_tiles) return;
+  const long long ia = (long long)wave * a.tile;
+  long long ib = ia + a.tile;
+  if (ib > a.n) ib = a.n;
+  const size_t o = (size_t)k * a.n_tiles + wave;
+  const int2 rng = a.ranges[o];
+  const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
+  int first = rng.y, last = rng.y;  // nothing reaches: empty range
+  for (int base = rng.x; base < rng.y; base += 64) {
+    const int s = base + lane;
+    const bool reach = s < rng.y && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
+    const unsigned long long m = __ballot(reach);
+    if (m) { first = base + __builtin_ctzll(m); break; }
+  }
+  if (first < rng.y) {
+    for (int top = rng.y; top > first; top -= 64) {
+      const int s = top - 1 - lane;
+      const bool reach = s >= first && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
+      const unsigned long long m = __ballot(reach);
+      if (m) { last = top - __builtin_ctzll(m); break; }
+    }
+  }
+  if (lane == 0) a.ranges[o] = make_int2(first, last);
+}
+
+int rtx_voigt_scatter_tile_points(void);
 // points per line-sum workgroup tile: capacity granularity of rtx_prep_create, and the alignment at which a wavenumber
 // shard reproduces the full grid's tiles (hence its bits: dist.hsi_cube_from_atmosphere)
 extern "C" int rtx_voigt_tile_points(void) { return rtx_voigt_scatter_tile_points(); }
@@ -56,9 +91,10 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
 
 static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_layers, int n_tiles, int tile, hipStream_t st) {
   RangeArgs ra;
-  ra.ic = P->ic; ra.maxhw = P->maxhw; ra.n_lines = P->n_lines; ra.n_tiles = n_tiles; ra.tile = tile;
+  ra.ic = P->ic; ra.maxhw = P->maxhw; ra.rec = P->rec; ra.n_lines = P->n_lines; ra.n_tiles = n_tiles; ra.tile = tile;
   ra.n_layers = n_layers; ra.n = grid->n; ra.ranges = P->ranges;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles + 255) / 256, n_layers), dim3(256), 0, st, ra);
+  hipLaunchKernelGGL(tile_trim_kernel, dim3((n_tiles + 3) / 4, n_layers), dim3(256), 0, st, ra);
 }
 
 // RADTXFR_VOIGT_KERNEL=scatter selects the point-by-point cross-check kernel instead of the default nodal one.

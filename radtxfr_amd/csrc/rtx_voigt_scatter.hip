@@ -25,9 +25,11 @@
 //                                by vector loads, no scalar work per line: ~1.6 VALU slots per (line, row)
 //                                against ~11 for the point-by-point form, and C3's windows are ~80 rows wide.
 //
-// Summation order: a point's value is a fixed function of the tiling; a different tiling (a wavenumber shard that
-// does not start on a tile boundary) regroups the fp32 sums and may differ in the last bits (tests allow 3e-6; shards
-// aligned to the tile, as dist.py cuts them, are bit-identical to the single-rank result).
+// Summation order: a point's value is a fixed function of the tiling and of the lines that reach the tile (the candidate
+// ranges are trimmed to those, rtx_voigt.hip: tile_trim_kernel). A wavenumber shard that starts on a tile boundary of the
+// full axis -- dist.tile_aligned_bounds cuts every shard that way: compute_TUD_sharded, hsi_cube_from_atmosphere, bench.py
+// -- is therefore bit-identical to the single-rank result, whatever subset of the table the rank uploaded, provided the
+// subset holds every line in reach. A shard cut elsewhere regroups the fp32 sums (last-bit differences, ~1e-6).
 #include "rtx_common.h"
 
 #include "rtx_voigt_math.h"
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(64 * SC_NW, SMALLY ? RTX_SC_WAVES_SMALLY : RTX_SC_W
   }
 }
 
-extern "C" int rtx_voigt_scatter_tile_points(void) { return 64 * RTX_SC_ROWS; }
+__attribute__((visibility("hidden"))) int rtx_voigt_scatter_tile_points(void) { return 64 * RTX_SC_ROWS; }
 
 int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64, int64_t ld,
                           hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t),

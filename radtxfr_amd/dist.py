@@ -7,8 +7,15 @@ can reach its chunk (engine.max_wing_cm) and evaluates grid values bit-identical
 (rtx_grid carries the global offset). The only exchange is the final all-gather of the packed
 [tau, L-up, L-down] chunk (3 x nX/G floats per rank: 8.25 MB at G = 8 on the C3 grid).
 
-The reference has no multi-GPU code; its only parallel axis is multiprocessing.Pool over atmospheres
-(Generate_LWIR_TUD.py:117-150), which maps to independent replicas and needs no code here.
+Shards are cut on LINE-SUM TILE boundaries of the full axis (tile_aligned_bounds): a rank's tiles are then
+tiles of the single-rank run, its candidate ranges are trimmed to the lines that reach each tile
+(csrc/rtx_voigt.hip), and its results are bit-identical to the single-rank run for any number of ranks.
+Shard lengths are weighted by a per-tile cost estimate (engine.tile_costs: lines in reach, line centres and
+Weideman band rows per tile, all layers), because equal lengths leave the rank with the highest wavenumbers
+-- widest Doppler cores, most band rows -- as the straggler of every step.
+
+The reference's own parallel axis is multiprocessing.Pool over atmospheres (Generate_LWIR_TUD.py:117-150):
+independent replicas, radiative_transfer.compute_TUD_batch(devices=...) from one process.
 """
 import numpy as np
 import torch
@@ -16,10 +23,36 @@ import torch.distributed as dist
 
 
 def shard_bounds(n_total, world, rank):
-    """Contiguous equal chunks of ceil(n_total/world) points (the last rank may be short or empty)."""
+    """Contiguous equal chunks of ceil(n_total/world) items (the last rank may be short or empty): (offset, count,
+    per). Used for axes with no tile structure (MAKO bands, rows)."""
     per = (int(n_total) + world - 1) // world
     off = min(rank * per, int(n_total))
     return off, max(0, min(per, int(n_total) - off)), per
+
+
+def tile_aligned_bounds(n_total, world, tile, cost=None):
+    """Offsets [world + 1] of contiguous wavenumber shards: offs[0] = 0, offs[world] = n_total, every interior
+    offset a multiple of `tile` (the line-sum tile, rtx_voigt_tile_points()). cost [n_tiles] (any positive
+    per-tile weights, e.g. engine.tile_costs) balances the shards' summed cost; None = equal tile counts.
+    Deterministic: every rank computes the same cut from the same inputs. Trailing shards may be empty when
+    there are fewer tiles than ranks."""
+    n_total, world, tile = int(n_total), int(world), int(tile)
+    n_tiles = (n_total + tile - 1) // tile
+    c = np.ones(n_tiles) if cost is None else np.maximum(np.asarray(cost, dtype=np.float64).ravel(), 0.0)
+    assert c.size == n_tiles, (c.size, n_tiles)
+    if not np.any(c > 0):
+        c = np.ones(n_tiles)
+    cum = np.concatenate([[0.0], np.cumsum(c)])
+    cuts = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        j = int(np.searchsorted(cum, target, side="left"))  # first j with cum[j] >= target
+        if j > 0 and target - cum[j - 1] < cum[min(j, n_tiles)] - target:
+            j -= 1  # the nearer of the two neighbouring tile boundaries
+        cuts.append(min(max(j, cuts[-1]), n_tiles))
+    offs = np.minimum(np.asarray(cuts + [n_tiles], dtype=np.int64) * tile, n_total)
+    offs[-1] = n_total
+    return offs
 
 
 def subset_lines(columns, x_lo, x_hi, reach):
@@ -42,44 +75,71 @@ def _all_gather_flat(send, world, group=None):
     return recv
 
 
-def all_gather_spectra(local, n_total, group=None):
+def all_gather_spectra(local, n_total, group=None, offs=None):
     """local: [C][n_loc] tensor (C stacked spectra of this rank's chunk, any device the backend supports).
-    Returns [C][n_total] on every rank. One all_gather_into_tensor of a padded [C][per] block."""
+    Returns [C][n_total] on every rank. One all_gather_into_tensor of a padded [C][per] block. offs [world + 1]:
+    the shard offsets (tile_aligned_bounds); None = shard_bounds' equal chunks."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local[:, :n_total]
     rank = dist.get_rank(group)
-    off, n_loc, per = shard_bounds(n_total, world, rank)
+    if offs is None:
+        per0 = (int(n_total) + world - 1) // world
+        offs = np.minimum(np.arange(world + 1, dtype=np.int64) * per0, int(n_total))
+    offs = np.asarray(offs, dtype=np.int64)
+    lens = np.diff(offs)
+    per = int(lens.max())
+    n_loc = int(lens[rank])
     assert local.shape[1] == n_loc, (local.shape, n_loc)
     C = local.shape[0]
     send = local if n_loc == per else torch.nn.functional.pad(local, (0, per - n_loc))
     send = send.contiguous().view(-1)  # flat buffers: accepted by both the RCCL and the gloo backends
-    recv = _all_gather_flat(send, world, group)
-    return recv.view(world, C, per).permute(1, 0, 2).reshape(C, world * per)[:, :n_total]
+    recv = _all_gather_flat(send, world, group).view(world, C, per)
+    if np.all(lens[:-1] == per):  # equal chunks, ragged tail only: one strided view
+        return recv.permute(1, 0, 2).reshape(C, world * per)[:, :n_total]
+    return torch.cat([recv[r, :, :int(lens[r])] for r in range(world)], dim=1)
 
 
-def sharded_tud(compute_local, columns, Xmin, Xmax, n_total, reach, group=None):
+def sharded_tud(compute_local, columns, Xmin, Xmax, n_total, reach, group=None, offs=None):
     """Run `compute_local(sub_table, offset, n_loc) -> [3][n_loc] tensor (tau, Lu, Ld)` on this rank's
     chunk of np.linspace(Xmin, Xmax, n_total) and reassemble the full spectra on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    off, n_loc, _ = shard_bounds(n_total, world, rank)
+    if offs is None:
+        per0 = (int(n_total) + world - 1) // world
+        offs = np.minimum(np.arange(world + 1, dtype=np.int64) * per0, int(n_total))
+    off, n_loc = int(offs[rank]), int(offs[rank + 1] - offs[rank])
     step = (Xmax - Xmin) / (n_total - 1)
     x_lo, x_hi = Xmin + off * step, Xmin + (off + max(n_loc, 1) - 1) * step
     sub = subset_lines(columns, x_lo, x_hi, reach)
     local = compute_local(sub, off, n_loc)
-    return all_gather_spectra(local, n_total, group)
+    return all_gather_spectra(local, n_total, group, offs)
+
+
+def tud_shard_plan(line_table, Xmin, Xmax, n_total, Ts, Ps, world, balance=True):
+    """(offs [world + 1], reach [cm^-1]) for a wavenumber-sharded compute_TUD: tile-aligned shards of the axis
+    np.linspace(Xmin, Xmax, n_total), weighted by engine.tile_costs when `balance`; `reach` = how far outside its
+    shard a rank must keep line centres. Pure host arithmetic on the table's columns: identical on every rank."""
+    from . import _lib, engine
+    tile = int(_lib.load().rtx_voigt_tile_points())
+    p_atm = np.asarray(Ps, dtype=np.float64) / 101325.0
+    step = (Xmax - Xmin) / (n_total - 1)
+    reach = engine.max_wing_cm(line_table, Ts, p_atm) + step
+    cost = engine.tile_costs(line_table, Xmin, step, n_total, Ts, p_atm, tile) if (balance and world > 1) else None
+    return tile_aligned_bounds(n_total, world, tile, cost), reach
 
 
 def compute_TUD_sharded(Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, PLs, MFs_VAL, MFs_ID, Altitudes=(500,), theta_r=0.0,
-                        N_angle=30, group=None):
+                        N_angle=30, group=None, balance=True):
     """compute_TUD (radiative_transfer.py:274-392) with the spectral axis sharded over the ranks of
     `group`; every rank returns the full (X, tau, Lu, Ld) as float32 device tensors (X as NumPy fp64).
-    One sensor altitude / slant path per call."""
+    One sensor altitude / slant path per call. Shards are tile-aligned (tud_shard_plan): the spectra are
+    bit-identical for every world size, including 1."""
     from . import engine
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     n_total = int(np.ceil((Xmax - Xmin) / DVOUT))
     grid_full = engine.Grid(Xmin, Xmax, n_total)
-    reach = engine.max_wing_cm(line_table, Ts, np.asarray(Ps, dtype=np.float64) / 101325.0) + grid_full.step
+    offs, reach = tud_shard_plan(line_table, Xmin, Xmax, n_total, Ts, Ps, world, balance)
 
     def compute_local(sub, off, n_loc):
         dev = engine.device()
@@ -95,7 +155,7 @@ def compute_TUD_sharded(Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, PLs, MFs_VAL,
             torch.cuda.synchronize()
             lines.close()
 
-    full = sharded_tud(compute_local, line_table, Xmin, Xmax, n_total, reach, group)
+    full = sharded_tud(compute_local, line_table, Xmin, Xmax, n_total, reach, group, offs)
     return np.linspace(Xmin, Xmax, n_total), full[0], full[1], full[2]
 
 

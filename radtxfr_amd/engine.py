@@ -107,6 +107,7 @@ class LineTable:
     def __init__(self, columns):
         require_gpu()
         lib = _lib.load()
+        self.device = torch.cuda.current_device()  # the table lives on the device that is current at creation
         nu = np.asarray(columns["nu"], dtype=np.float64)
         order = np.argsort(nu, kind="stable")
         self.n = int(nu.size)
@@ -134,6 +135,7 @@ class LineTable:
             if k in columns:
                 sd[k] = np.ascontiguousarray(np.asarray(columns[k], dtype=np.float64)[order])
                 self.has_sd = self.has_sd or bool(np.any(sd[k] != 0.0))
+        self._sd = sd
         if self.has_sd:
             sp_ = lambda k: sd[k].ctypes.data_as(C.c_void_p) if k in sd else C.c_void_p(0)
             _lib.check(lib.rtx_lines_set_sd(self._h, sp_("SD_air"), sp_("SD_self")))
@@ -143,6 +145,24 @@ class LineTable:
                 self.cols["deltap_self"] = dps
                 _lib.check(lib.rtx_lines_set_deltap_self(self._h, dps.ctypes.data_as(C.c_void_p)))
         self._plans = {}
+
+    def host_columns(self):
+        """The uploaded columns as a host column dict (sorted by nu): what another device's copy is built from."""
+        cols = dict(self.cols)
+        cols.update(self._sd)
+        cols["molec_id"], cols["local_iso_id"] = self.molec_id, self.local_iso_id
+        return cols
+
+    def on_device(self, dev):
+        """This table on device index `dev`: itself, or a cached copy uploaded there (closed with this table)."""
+        dev = int(dev)
+        if dev == self.device:
+            return self
+        peers = self.__dict__.setdefault("_peers", {})
+        if dev not in peers:
+            with torch.cuda.device(dev):
+                peers[dev] = LineTable(self.host_columns())
+        return peers[dev]
 
     def plan(self, n_layers, n_points):
         """A prep object big enough for (n_layers, n_points); cached, grown on demand."""
@@ -157,11 +177,14 @@ class LineTable:
         return best
 
     def close(self):
+        for t in self.__dict__.pop("_peers", {}).values():
+            t.close()
         for p in self._plans.values():
             p.close()
         self._plans = {}
         if self._h:
-            _lib.load().rtx_lines_free(self._h)
+            with torch.cuda.device(self.device):
+                _lib.load().rtx_lines_free(self._h)
             self._h = C.c_void_p(0)
 
     def __del__(self):
@@ -320,15 +343,25 @@ def tud(OD, grid, T, Z, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=Fals
     if mu_s.size > TUD_MAX_MU:
         # more slant paths than one launch takes (radiative_transfer.py:346-356 loops over any number): blocks of
         # TUD_MAX_MU, each a launch of its own; the downwelling (independent of mu) is simply recomputed
-        assert out is None and not per_angle, "out= / per_angle are limited to %d slant paths" % TUD_MAX_MU
+        if out is not None:
+            raise ValueError("engine.tud: out= is limited to %d slant paths per call" % TUD_MAX_MU)
         th = np.asarray(theta_r, dtype=np.float64).ravel()
         tau = torch.empty((Z_s.size, mu_s.size, grid.n), dtype=torch.float32, device=OD.device)
         Lu = torch.empty_like(tau)
+        Ld_ang = None
         for m0 in range(0, mu_s.size, TUD_MAX_MU):
             m1 = min(m0 + TUD_MAX_MU, mu_s.size)
-            t_c, l_c, Ld, _ = tud(OD, grid, T, Z, Altitudes=Altitudes, theta_r=th[m0:m1], N_angle=N_angle, returnOD=returnOD)
+            # the per-stream downwelling radiances do not depend on the slant paths: taken from the first block
+            res = tud(OD, grid, T, Z, Altitudes=Altitudes, theta_r=th[m0:m1], N_angle=N_angle, returnOD=returnOD,
+                      per_angle=per_angle and m0 == 0)
+            t_c, l_c, Ld_c = res[:3]
+            if m0 == 0:
+                Ld = Ld_c
+                Ld_ang = res[4] if per_angle else None
             tau[:, m0:m1] = t_c.view(Z_s.size, m1 - m0, grid.n)
             Lu[:, m0:m1] = l_c.view(Z_s.size, m1 - m0, grid.n)
+        if per_angle:
+            return tau.view(-1, grid.n), Lu.view(-1, grid.n), Ld, (Z_s.size, mu_s.size), Ld_ang
         return tau.view(-1, grid.n), Lu.view(-1, grid.n), Ld, (Z_s.size, mu_s.size)
     mask = np.ascontiguousarray(np.stack([(Z <= zs) for zs in Z_s]).astype(np.uint8))
     n_down = int(mask[-1].sum())  # quirk 3: nL is overwritten by the LAST altitude's count (:353, :370)
@@ -365,7 +398,7 @@ class TudRunner:
     by the next run(): tau, Lu [nAlt*nMu][n], Ld [n], OD [nL][n]."""
 
     def __init__(self, lines, grid, Z, n_layers=None, Altitudes=(500,), theta_r=0.0, N_angle=30, returnOD=False, out=None,
-                 OD=None):
+                 OD=None, plan=None):
         self.lib = _lib.load()
         self.lines, self.grid = lines, grid
         Z = np.atleast_1d(np.asarray(Z, dtype=np.float64))
@@ -388,7 +421,9 @@ class TudRunner:
         else:
             self.tau, self.Lu, self.Ld = out
         self.set_outputs(self.tau, self.Lu, self.Ld)
-        self.plan = lines.plan(self.nL, grid.n)
+        # plan: a VoigtPlan of the caller's (two pipelines on one device must not share per-(line, layer) records);
+        # default = the table's cached plan, shared by everything that runs on the device's current stream
+        self.plan = plan if plan is not None else lines.plan(self.nL, grid.n)
         self._env = np.empty(2 * self.nL + 2 * len(lines.species) * self.nL + len(lines.species), dtype=np.float64)
 
     def set_outputs(self, tau, Lu, Ld):
@@ -477,6 +512,57 @@ def max_wing_cm(columns, T_layers, p_atm_layers, omega_wing=0.0, omega_wing_hw=5
     gd = 3.6e-7 * float(np.max(nu)) * np.sqrt(float(np.max(T)) / 1.0)  # mass >= 1 g/mol: generous
     shift = float(np.max(np.abs(columns["delta_air"]))) * float(np.max(p))
     return max(float(omega_wing), omega_wing_hw * g0, omega_wing_hw * min(gd, 10.0 * g0 + 1.0)) + shift
+
+
+# Relative cost of one line-sum tile, fitted (non-negative least squares) to the step time of 32 contiguous chunks of the
+# C3 grid on MI355X (tools/shard_balance.py, profiles/r3_shard_balance.txt): per line whose window reaches the tile
+# (classification + row-level evaluations) and per Weideman band row; the line centres' near-zone rows come out
+# collinear with the reach count (0), and the per-(tile, layer) constant (zeroing, interpolation, stores, the TUD pass)
+# cannot be told from the per-launch constant on equal chunks -- a small value keeps empty spans from costing nothing.
+TILE_COST = {"tile": 100.0, "reach": 30.0, "centre": 0.0, "band_row": 24.0}
+
+
+def tile_costs(columns, xmin, step, n_total, T_layers, p_atm_layers, tile, omega_wing=0.0, omega_wing_hw=50.0, coef=None):
+    """Estimated line-sum + TUD cost of every `tile`-point tile of the axis xmin + i*step, i < n_total, summed over the
+    layers: cost[n_tiles]. Host arithmetic on the table's columns only (windows W = max(OmegaWing, HW*gamma0, HW*gammaD),
+    misc/hapi.py:11131; band half-width (15 - y)/cte where y < 15, :9840) -- the same on every rank. Used to cut
+    wavenumber shards of equal COST rather than equal length (dist.tile_aligned_bounds)."""
+    c = dict(TILE_COST)
+    if coef:
+        c.update(coef)
+    T = np.atleast_1d(np.asarray(T_layers, dtype=np.float64))
+    p = np.atleast_1d(np.asarray(p_atm_layers, dtype=np.float64))
+    n_tiles = (int(n_total) + int(tile) - 1) // int(tile)
+    cost = np.full(n_tiles, c["tile"] * T.size)
+    nu = np.asarray(columns["nu"], dtype=np.float64)
+    if nu.size == 0:
+        return cost
+    ga = np.asarray(columns["gamma_air"], dtype=np.float64)
+    na = np.asarray(columns["n_air"], dtype=np.float64)
+    M = np.asarray(columns["molec_id"]).astype(np.int64)
+    I = np.asarray(columns["local_iso_id"]).astype(np.int64)
+    mass = np.ones(nu.size)
+    for mi in set(zip(M.tolist(), I.tolist())):
+        try:
+            mass[(M == mi[0]) & (I == mi[1])] = tips.molecularMass(*mi)
+        except Exception:
+            pass  # unknown isotopologue: the default only skews the estimate
+    span = float(step) * int(tile)
+    tc = np.floor((nu - xmin) / span).astype(np.int64)  # tile of the line centre
+    inside = (tc >= 0) & (tc < n_tiles)
+    sqln2 = np.sqrt(np.log(2.0))
+    for k in range(T.size):
+        g0 = ga * p[k] * (TREF / T[k]) ** na
+        gd = np.sqrt(2.0 * CBOLTS * T[k] * np.log(2.0) / (mass * 1.66053873e-27 * 1000.0) / 2.99792458e10 ** 2) * nu
+        W = np.maximum(omega_wing, np.maximum(omega_wing_hw * g0, omega_wing_hw * gd))
+        t_lo = np.clip(np.floor((nu - W - xmin) / span), 0, n_tiles).astype(np.int64)
+        t_hi = np.clip(np.floor((nu + W - xmin) / span) + 1, 0, n_tiles).astype(np.int64)
+        d = np.bincount(t_lo, minlength=n_tiles + 1)[:n_tiles + 1] - np.bincount(t_hi, minlength=n_tiles + 1)[:n_tiles + 1]
+        cost += c["reach"] * np.cumsum(d)[:n_tiles]
+        y = g0 * sqln2 / gd
+        rows = np.where(y < 15.0, 2.0 * (15.0 - y) * gd / sqln2 / (64.0 * step) + 1.0, 0.0)
+        cost += np.bincount(tc[inside], weights=(c["centre"] + c["band_row"] * rows)[inside], minlength=n_tiles)[:n_tiles]
+    return cost
 
 
 # ---- post-processing: smooth / reduceResolution (rtx_fir_reflect, rtx_cubic_resample) ------------

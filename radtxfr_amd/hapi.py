@@ -35,8 +35,13 @@ _DEVICE_TABLES_MAX = 8
 def storage2cache_from_columns(TableName, columns):
     """Convenience: register a column dict as a table (what db_begin()/fetch() leave in the cache)."""
     n = len(columns["nu"])
+    # numeric columns are kept as ndarrays (as hitran_par.storage2cache does): the reference's Python lists would cost a
+    # list -> array conversion of every column on every call (~50 ms for 100 000 rows, ten times the device time)
+    def keep(v):
+        a = np.asarray(v)
+        return a.copy() if a.dtype.kind in "fiub" else list(v)
     LOCAL_TABLE_CACHE[TableName] = {"header": {"number_of_rows": n, "table_name": TableName},
-                                    "data": {k: (v.tolist() if hasattr(v, "tolist") else list(v)) for k, v in columns.items()}}
+                                    "data": {k: keep(v) for k, v in columns.items()}}
 
 
 _USED_COLS = ("molec_id", "local_iso_id", "nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air",
@@ -56,7 +61,15 @@ def _column_signature(v, nrow):
         if len(_SIG_WEIGHTS) > 16:
             _SIG_WEIGHTS.clear()
         w = _SIG_WEIGHTS[a.size] = np.random.default_rng(12345).uniform(0.5, 1.5, a.size)
-    return (a.size, float(np.dot(a, w)) if a.size else 0.0)
+    if not a.size:
+        return (0, 0.0)
+    d = float(np.dot(a, w))
+    if d != d:
+        # a NaN in the column (e.g. a blank field of a .par record): NaN never compares equal, which would rebuild the
+        # device table on every call. Fingerprint the finite part and the positions of the NaNs instead.
+        bad = np.isnan(a.astype(np.float64, copy=False))
+        return (a.size, float(np.dot(np.where(bad, 0.0, a), w)), float(np.dot(bad, w)))
+    return (a.size, d)
 
 
 def _device_table(names):

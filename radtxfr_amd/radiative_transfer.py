@@ -24,11 +24,12 @@ Conscious divergences from the reference:
   * spectra are computed in float32 on the device and returned as float64.
 """
 import os
+import threading
 
 import numpy as np
 import torch
 
-from . import engine
+from . import _hostio, engine
 from . import hapi as _hapi
 
 # Module constants (radiative_transfer.py:71-72)
@@ -50,6 +51,7 @@ options = {
     "T": 296.0, "P": 101325.0, "PL": 1.0,
     "MF_ID": np.array([]), "MF_VAL": np.array([]),
     "line_table": None,  # replaces "LBLRTM"/"TAPE3": name in hapi.LOCAL_TABLE_CACHE or column dict
+    "copy_axis": False,  # True: compute_TUD returns a fresh writable X (the reference's behaviour) instead of a cached read-only one
     # options for compute_TUD (:172-182)
     "Zs": StdAtmos[:, 1], "Ts": StdAtmos[:, 5], "Ps": StdAtmos[:, 4], "PLs": StdAtmos[:, 3],
     "MFs_VAL": StdAtmos[:, 6:14] * 1e6, "MFs_ID": np.array([1, 2, 3, 4, 5, 6, 7, 22]),
@@ -192,33 +194,23 @@ def _cached_axis(Xmin, Xmax, DVOUT):
     return X
 
 
+_STAGING = {}
+
+
 def _rows_to_host_f64(rows, stream=None):
-    """float32 device rows [(k_i, n)] -> float64 NumPy arrays: widened on the DEVICE into one block, one asynchronous copy
-    into pinned host memory (PyTorch's caching pinned allocator: no allocation after the first call of a size), views handed
-    out. Returns (arrays, event): the arrays are valid once `event` has completed (event.synchronize())."""
-    n = rows[0].shape[-1]
-    ks = [int(np.prod(r.shape[:-1])) if r.dim() > 1 else 1 for r in rows]
-    dev_block = torch.empty((sum(ks), n), dtype=torch.float64, device=rows[0].device)
-    o = 0
-    for r, k in zip(rows, ks):
-        dev_block[o:o + k].copy_(r.reshape(k, n))
-        o += k
-    host = torch.empty((sum(ks), n), dtype=torch.float64, pin_memory=True)
-    side = stream if stream is not None else torch.cuda.current_stream()
-    ready = torch.cuda.Event()
-    ready.record()  # the widening runs on the current (compute) stream
-    with torch.cuda.stream(side):
-        side.wait_event(ready)
-        host.copy_(dev_block, non_blocking=True)
-        dev_block.record_stream(side)
-        done = torch.cuda.Event()
-        done.record(side)
-    arr = host.numpy()
-    out, o = [], 0
-    for k in ks:
-        out.append(arr[o:o + k])
-        o += k
-    return out, done
+    """float32 device rows [(k_i, n)] -> float64 NumPy arrays (see _hostio): zero-copy views of a pinned block while the
+    pinned bytes lent out stay under _hostio.PINNED_RESULT_CAP, else fresh pageable arrays filled from a reusable pinned
+    staging ring by the host thread pool. Returns (arrays, event): the arrays are valid once `event` has completed
+    (event.synchronize()); on the pageable path they are complete on return."""
+    got = _hostio.rows_to_pinned_f64(rows, stream)
+    if got is not None:
+        return got
+    key = (rows[0].device.index, threading.get_ident())
+    st = _STAGING.get(key)
+    if st is None:
+        st = _STAGING[key] = _hostio.Staging(depth=1)
+    ticket = st.stage(rows, stream)
+    return st.collect(ticket), ticket[3]
 
 
 def _tud_shapes(tau2, Lu2, nZ, nMu):
@@ -242,7 +234,9 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     (nX,nZ,nMu) by the reference's squeeze rules (:357-365); Ld is (nX,).
     Quirks 3-6 of SURVEY.md section 9 are reproduced (downwelling uses the layer count of the last
     sensor altitude; tau uses the Z<=zs mask, L-up the first count layers; returnOD; theta=0 weight 0).
-    X is a cached read-only array (see _cached_axis); the spectra are fresh float64 arrays in pinned host memory.
+    X is a cached read-only array (see _cached_axis; copy_axis=True gives the reference's fresh writable one); the
+    spectra are fresh float64 arrays -- views of page-locked memory while less than _hostio.PINNED_RESULT_CAP is lent
+    out to live results, ordinary pageable arrays beyond that.
     """
     o = dict(opts)
     o.update(kwargs)
@@ -259,6 +253,8 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     X_ = _cached_axis(Xmin, Xmax, o["DVOUT"])
     grid = engine.Grid(Xmin, Xmax, X_.size)
     tbl = _resolve_table(o.get("line_table"))
+    if o.get("copy_axis"):
+        X_ = _hostio.copy_threaded(X_)
     if mu_s.size <= engine.TUD_MAX_MU and not o["save"]:
         # the common case: one call into the library (rtx_compute_tud)
         run = engine.TudRunner(tbl, grid, Z, n_layers=T.size, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64),
@@ -284,22 +280,83 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     return X_, tau_, Lu_, Ld_
 
 
-def compute_TUD_batch(Xmin, Xmax, atmospheres, opts=options, reduce=None, **kwargs):
+class _TudPipeline:
+    """One device's share of compute_TUD_batch: the line table's copy on that device, two runners (two sets of device
+    outputs: the copy of one is in flight while the other is being computed) on a compute stream of its own, a side
+    stream for the device-to-host copies, a pinned staging ring."""
+
+    def __init__(self, dev, tbl, grid, Z, nL, Z_s, theta_r, N_angle, returnOD):
+        self.dev = int(dev)
+        with torch.cuda.device(self.dev):
+            self.lines = tbl.on_device(self.dev)
+            self.compute = torch.cuda.Stream()
+            self.side = torch.cuda.Stream()
+            # a plan of its own: another pipeline may share the device (and the table's cached plan)
+            self.plan = engine.VoigtPlan(self.lines, nL, grid.n)
+            mk = lambda OD: engine.TudRunner(self.lines, grid, Z, n_layers=nL, Altitudes=Z_s, theta_r=theta_r, N_angle=N_angle,
+                                             returnOD=returnOD, OD=OD, plan=self.plan)
+            self.runs = [mk(None)]
+            self.runs.append(mk(self.runs[0].OD))  # the layer optical depths are consumed on the compute stream: one buffer
+        self.busy = [None, None]  # copy-done event of each runner's outputs
+        self.staging = _hostio.Staging(depth=2)
+        self.k = 0
+
+    def enqueue(self, a, ID, grid, x0, reduce, full_dtype):
+        """Kernels + device-to-host copy of one atmosphere, all asynchronous. Returns a ticket for finish()."""
+        j = self.k & 1
+        self.k += 1
+        run = self.runs[j]
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.compute):
+            if self.busy[j] is not None:
+                self.compute.wait_event(self.busy[j])  # its previous outputs have left the device
+            tau, Lu, Ld = run.run(np.asarray(a["Ts"], dtype=np.float64), np.asarray(a["Ps"], dtype=np.float64),
+                                  np.asarray(a["PLs"], dtype=np.float64), np.asarray(a["MFs_VAL"], dtype=np.float64), ID)
+            Xr = None
+            if reduce is not None:
+                rows = torch.cat([tau, Lu, Ld[None, :]])
+                Xr, red = engine.reduce_resolution(rows, x0, grid.step, grid.n, float(reduce["dX"]), N=reduce.get("N", 4),
+                                                   window=reduce.get("window", "hanning"))
+                nr = tau.shape[0]
+                t = self.staging.stage([red[:nr], red[nr:2 * nr], red[2 * nr:]], stream=self.side)
+            else:
+                t = self.staging.stage([tau, Lu, Ld[None, :]], stream=self.side)
+            self.busy[j] = t[3]
+        return t, Xr
+
+    def finish(self, ticket, dtype):
+        with torch.cuda.device(self.dev):
+            return self.staging.collect(ticket, dtype)
+
+    def close(self):
+        with torch.cuda.device(self.dev):
+            torch.cuda.synchronize()
+            self.plan.close()
+
+
+def compute_TUD_batch(Xmin, Xmax, atmospheres, opts=options, reduce=None, devices=None, out_dtype=np.float64, **kwargs):
     """compute_TUD for MANY atmospheres on one spectral grid -- the reference's outer loop
     (Generate_LWIR_TUD.py:117-150: 199 atmospheres x `rt.compute_TUD(..., MFs_VAL=, Ts=, ...)`, fanned out over a
-    multiprocessing.Pool there) as a device pipeline: atmosphere k's widening and device-to-host copy run on a side stream
-    while atmosphere k+1's kernels run on the compute stream.
+    multiprocessing.Pool(6) there) as device pipelines driven by ONE host process: atmosphere k's device-to-host copy
+    runs on a side stream while the next atmosphere's kernels run on the compute stream.
 
     atmospheres: sequence of dicts with any of Ts, Ps, PLs, MFs_VAL (the per-atmosphere kwargs of the reference's caller);
     everything else (Zs, MFs_ID, DVOUT, Altitudes, theta_r, N_angle, returnOD, line_table) comes from opts / kwargs and is
     common to the batch. reduce = dict(dX=..., N=4, window="hanning") applies reduceResolution (:1327-1350) to tau, Lu and
     Ld on the device, as the reference's caller does right after each compute_TUD (Generate_LWIR_TUD.py:124-126): only the
     reduced spectra cross PCIe then.
-    Returns a list of (X, tau, Lu, Ld) with the shapes compute_TUD gives (X_out instead of X when reduce is set)."""
+    devices: GPU indices to spread the atmospheres over (the reference's Pool axis without a launcher): atmosphere k goes
+    to devices[k % len(devices)]; the line table is uploaded once per distinct device; an index may repeat (independent
+    pipelines sharing a device). None = the current device. Results come back in input order and are bit-identical to
+    per-call compute_TUD whatever the devices.
+    out_dtype: float64 (the reference's) or float32 (half the host work when full spectra are kept).
+    Returns a list of (X, tau, Lu, Ld) with the shapes compute_TUD gives (X_out instead of X when reduce is set); the
+    arrays are ordinary pageable NumPy arrays (float32 crosses PCIe into a reusable pinned ring, a host thread pool widens)."""
     o = dict(opts)
     o.update(kwargs)
     if o["save"]:
         raise ValueError("compute_TUD_batch: save is a single-call option")
+    if np.dtype(out_dtype) not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise ValueError("compute_TUD_batch: out_dtype must be float64 or float32")
     Z = np.asarray(o["Zs"], dtype=np.float64)
     ID = np.asarray(o["MFs_ID"])
     f = lambda x: np.array([x]).ravel()
@@ -307,50 +364,42 @@ def compute_TUD_batch(Xmin, Xmax, atmospheres, opts=options, reduce=None, **kwar
     mu_s = f(1.0 / np.cos(o["theta_r"]))
     if mu_s.size > engine.TUD_MAX_MU:
         raise ValueError("compute_TUD_batch takes at most %d slant paths" % engine.TUD_MAX_MU)
+    engine.require_gpu()
+    devs = [torch.cuda.current_device()] if devices is None else [int(d) for d in devices]
+    if not devs or any(d < 0 or d >= torch.cuda.device_count() for d in devs):
+        raise ValueError("compute_TUD_batch: devices=%r, visible GPUs: %d" % (devices, torch.cuda.device_count()))
     X_ = _cached_axis(Xmin, Xmax, o["DVOUT"])
     grid = engine.Grid(Xmin, Xmax, X_.size)
-    tbl = _resolve_table(o.get("line_table"))
+    with torch.cuda.device(devs[0]):
+        tbl = _resolve_table(o.get("line_table"))
     nL = np.asarray(o["Ts"]).size
-    # two runners = two sets of device outputs: the copy of one is in flight while the other is being computed
-    mk = lambda OD: engine.TudRunner(tbl, grid, Z, n_layers=nL, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64),
-                                     N_angle=int(o["N_angle"]), returnOD=bool(o["returnOD"]), OD=OD)
-    runs = [mk(None)]
-    runs.append(mk(runs[0].OD))  # the layer optical depths are consumed on the compute stream: one buffer is enough
-    nZ, nMu = runs[0].shape
-    side = torch.cuda.Stream()
-    busy = [None, None]     # copy-done event of the runner's outputs
-    pending = []            # (host rows, done event, X of the result)
+    theta = np.asarray(o["theta_r"], dtype=np.float64)
+    pipes = [_TudPipeline(d, tbl, grid, Z, nL, Z_s, theta, int(o["N_angle"]), bool(o["returnOD"])) for d in devs]
+    nZ, nMu = pipes[0].runs[0].shape
+    pending = []  # (pipeline, ticket, X of the result) in input order
     results = []
 
     def finish(item):
-        (tau_h, Lu_h, Ld_h), done, Xr = item
-        done.synchronize()
+        pipe, ticket, Xr = item
+        tau_h, Lu_h, Ld_h = pipe.finish(ticket, np.dtype(out_dtype))
         tau_, Lu_ = _tud_shapes(tau_h, Lu_h, nZ, nMu)
         results.append((Xr, tau_, Lu_, Ld_h[0]))
 
-    for k, atm in enumerate(atmospheres):
-        a = dict(o)
-        a.update(atm)
-        run = runs[k & 1]
-        if busy[k & 1] is not None:
-            torch.cuda.current_stream().wait_event(busy[k & 1])  # its previous outputs have left the device
-        tau, Lu, Ld = run.run(np.asarray(a["Ts"], dtype=np.float64), np.asarray(a["Ps"], dtype=np.float64),
-                              np.asarray(a["PLs"], dtype=np.float64), np.asarray(a["MFs_VAL"], dtype=np.float64), ID)
-        Xr = X_
-        if reduce is not None:
-            rows = torch.cat([tau, Lu, Ld[None, :]])
-            Xr, red = engine.reduce_resolution(rows, float(X_[0]), grid.step, grid.n, float(reduce["dX"]), N=reduce.get("N", 4),
-                                               window=reduce.get("window", "hanning"))
-            nr = tau.shape[0]
-            host_rows, done = _rows_to_host_f64([red[:nr], red[nr:2 * nr], red[2 * nr:]], stream=side)
-        else:
-            host_rows, done = _rows_to_host_f64([tau, Lu, Ld[None, :]], stream=side)
-        busy[k & 1] = done
-        pending.append((host_rows, done, Xr))
-        if len(pending) > 1:
+    try:
+        for k, atm in enumerate(atmospheres):
+            a = dict(o)
+            a.update(atm)
+            pipe = pipes[k % len(pipes)]
+            ticket, Xr = pipe.enqueue(a, ID, grid, float(X_[0]), reduce, np.dtype(out_dtype))
+            pending.append((pipe, ticket, X_ if Xr is None else Xr))
+            # a pipeline's staging ring has two slots: the atmosphere staged two rounds ago on it must be collected first
+            while len(pending) > len(pipes):
+                finish(pending.pop(0))
+        while pending:
             finish(pending.pop(0))
-    while pending:
-        finish(pending.pop(0))
+    finally:
+        for p_ in pipes:
+            p_.close()
     return results
 
 

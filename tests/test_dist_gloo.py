@@ -86,6 +86,65 @@ def test_shard_bounds():
         assert all(got[r][0] == sum(g[1] for g in got[:r]) or got[r][1] == 0 for r in range(w))
 
 
+def test_tile_aligned_bounds():
+    """Interior offsets on tile boundaries, monotone, covering [0, n); a cost vector moves the cuts towards equal cost."""
+    for n, w, tile in ((5500000, 8, 1024), (3001, 2, 1024), (3001, 8, 1024), (700, 4, 1024), (1024 * 16, 4, 1024)):
+        o = rdist.tile_aligned_bounds(n, w, tile)
+        assert o.shape == (w + 1,) and o[0] == 0 and o[-1] == n and np.all(np.diff(o) >= 0)
+        assert all(v % tile == 0 for v in o[1:-1] if v < n)
+    n, tile = 5500000, 1024
+    nt = (n + tile - 1) // tile
+    cost = np.linspace(1.0, 3.0, nt)  # cost rising with wavenumber: shards must shrink towards the top
+    o = rdist.tile_aligned_bounds(n, 8, tile, cost)
+    lens = np.diff(o)
+    assert np.all(np.diff(lens) < 0)
+    share = np.array([cost[o[r] // tile:(o[r + 1] + tile - 1) // tile].sum() for r in range(8)]) / cost.sum()
+    assert np.max(np.abs(share - 0.125)) < 1e-3
+    assert np.array_equal(o, rdist.tile_aligned_bounds(n, 8, tile, cost))  # deterministic
+
+
+def test_tile_costs_follow_the_table():
+    """engine.tile_costs: more lines in reach -> more cost; Weideman band rows (high wavenumbers, low pressure) cost
+    extra; the C3 plan is tile-aligned and its shards shrink with wavenumber."""
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    a = synthetic.c3_atmosphere(8)
+    n = 5500000
+    step = 5500.0 / (n - 1)
+    c = engine.tile_costs(full, 500.0, step, n, a["Ts"], a["Ps"] / 101325.0, 1024)
+    assert c.shape == ((n + 1023) // 1024,) and np.all(c > 0)
+    assert c[-500:].mean() > c[:500].mean()  # wider Doppler cores at 6000 cm^-1
+    dense = {k: np.concatenate([v, v[(full["nu"] > 1000) & (full["nu"] < 1010)]]) for k, v in full.items()}
+    order = np.argsort(dense["nu"], kind="stable")
+    dense = {k: v[order] for k, v in dense.items()}
+    c2 = engine.tile_costs(dense, 500.0, step, n, a["Ts"], a["Ps"] / 101325.0, 1024)
+    t0 = int((1005.0 - 500.0) / step / 1024)
+    assert c2[t0] > 1.3 * c[t0] and abs(c2[10] - c[10]) < 1e-9 * c[10]
+    offs, reach = rdist.tud_shard_plan(full, 500.0, 6000.0, n, a["Ts"], a["Ps"], 8)
+    assert offs[0] == 0 and offs[-1] == n and all(v % 1024 == 0 for v in offs[1:-1]) and reach > 5.0
+    assert np.all(np.diff(np.diff(offs)) < 0)
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        offs = np.array([0, 2048, 3001])
+        full = torch.arange(3 * 3001, dtype=torch.float32).reshape(3, 3001)
+        got = rdist.all_gather_spectra(full[:, offs[rank]:offs[rank + 1]].clone(), 3001, offs=offs)
+        np.save(os.path.join(out_dir, f"u{rank}.npy"), got.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_uneven_tile_aligned_shards(tmp_path):
+    """all_gather_spectra with shards of different lengths (tile-aligned cuts): padded to the longest, one all-gather,
+    reassembled by the offsets."""
+    mp.spawn(_uneven_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = np.arange(3 * 3001, dtype=np.float32).reshape(3, 3001)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"u{r}.npy"), want)
+
+
 def test_world2_gloo_sharded_tud(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

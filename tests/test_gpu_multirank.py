@@ -46,9 +46,10 @@ def _run_ranks(mode, world, out_dir):
 
 
 def test_two_ranks_sharded_compute_tud(tmp_path):
-    """dist.compute_TUD_sharded on a C3 window, 3001 points over 2 ranks (ragged last shard): every rank ends up with
-    the full spectra; they equal the single-rank HIP result (1e-6: a different tiling regroups fp32 sums) and the
-    oracle (1e-5 / 2e-6)."""
+    """dist.compute_TUD_sharded on a C3 window, 3001 points over 2 ranks (tile-aligned shards, ragged last one, each
+    rank holding only the lines in reach of its shard): every rank ends up with the full spectra; they are BIT-IDENTICAL
+    to the single-rank HIP result (same tiles, candidate ranges trimmed to the reaching lines, same order of sums) and
+    within 1e-5 / 2e-6 of the oracle."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mp_worker
     from radtxfr_amd import dist as rdist
@@ -60,8 +61,8 @@ def test_two_ranks_sharded_compute_tud(tmp_path):
     for r in range(2):
         d = np.load(tmp_path / f"tud_r{r}.npz")
         assert np.array_equal(d["X"], Xr)
-        assert np.max(np.abs(d["tau"] - tau1.cpu().numpy())) <= 1e-6
-        assert rel_err(d["Lu"], Lu1.cpu().numpy()) <= 1e-6 and rel_err(d["Ld"], Ld1.cpu().numpy()) <= 1e-6
+        for key, one in (("tau", tau1), ("Lu", Lu1), ("Ld", Ld1)):
+            assert np.array_equal(d[key], one.cpu().numpy()), (key, float(np.max(np.abs(d[key] - one.cpu().numpy()))))
         assert np.max(np.abs(d["tau"] - tau_r)) <= TOL_TAU
         assert rel_err(d["Lu"], Lu_r) <= TOL_L and rel_err(d["Ld"], Ld_r) <= TOL_L
     d0, d1 = np.load(tmp_path / "tud_r0.npz"), np.load(tmp_path / "tud_r1.npz")
@@ -106,6 +107,20 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["config"]["n_wavenumbers"] == 5500000 and "checksum" in out and np.isfinite(out["checksum"]["tau_sum"])
+    sh = out["sharding"]
+    tile = 1024
+    assert len(sh["offsets"]) == 3 and sh["offsets"][0] == 0 and sh["offsets"][2] == 5500000 and sh["offsets"][1] % tile == 0
+    assert sum(sh["points_per_rank"]) == 5500000 and all(n < 100000 for n in sh["lines_per_rank"])  # per-rank line subsets
+    assert sh["collective_ms"] > 0 and sh["bytes_gathered"] == 2 * 3 * max(sh["points_per_rank"]) * 4
+    assert 0 < sh["kernel_ms"]["min"] <= sh["kernel_ms"]["max"] and len(sh["kernel_ms"]["per_rank"]) == 2
+    # the same workload on ONE rank: identical spectra, bit for bit (integer sums of the float32 bit patterns)
+    cmd1 = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    env1 = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res1 = subprocess.run(cmd1, env=env1, capture_output=True, text=True, timeout=600)
+    assert res1.returncode == 0, res1.stderr[-2000:]
+    out1 = json.loads([ln for ln in res1.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("tau_bits", "Lu_bits", "Ld_bits", "tau_sum", "Lu_sum", "Ld_sum"):
+        assert out["checksum"][key] == out1["checksum"][key], (key, out["checksum"][key], out1["checksum"][key])
     rec = os.environ.get("RADTXFR_REHEARSAL_RECORD")
     if rec:
         with open(rec, "w") as f:

@@ -510,6 +510,55 @@ def test_full_c3_width_properties():
     lines.close()
 
 
+def test_full_c3_stratified_windows_vs_oracle():
+    """The full C3 grid (5.5 M wavenumbers x 32 layers, the 100 000-line table) against the oracle on 14 windows of 1500
+    points STRATIFIED over 500-6000 cm^-1 -- five of them inside the LWIR span 500-1500 cm^-1, the first and the last tile
+    of the axis, a window across the middle tile boundary -- for the SURVEY-8d column (opaque almost everywhere) and the
+    same column with mixing ratios x 1e-3 (tau spans (0, 1)): optical depth of all 32 layers, tau, L-up, L-down at the
+    standing tolerances. (tools/acc_sweep.py as a driver-run test.)"""
+    import torch
+    from radtxfr_amd import engine
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    a = synthetic.c3_atmosphere(32)
+    lines = engine.LineTable(full)
+    grid = engine.Grid(500.0, 6000.0, 5500000)
+    starts = [0, 123456, 400000, 700000, 998500, 1500000, 2100000, 2750000 - 750, 3300000, 3900000, 4500000, 5000000, 5400000,
+              5500000 - 1500]
+    n = 1500
+    X = grid.axis()
+    assert sum(1 for i0 in starts if X[i0 + n - 1] <= 1500.0) >= 4
+    oracle = {}
+    worst = {}
+    for scale in (1.0, 1e-3):
+        mf = a["MFs_VAL"] * scale
+        OD = engine.optical_depths(lines, grid, a["Ts"], a["Ps"], a["PLs"], mf, a["MFs_ID"])
+        tau, Lu, Ld, _ = engine.tud(OD, grid, a["Ts"], a["Zs"])
+        torch.cuda.synchronize()
+        e = [0.0, 0.0, 0.0, 0.0]
+        spans = []
+        for i0 in starts:
+            Xw = X[i0:i0 + n]
+            if i0 not in oracle:
+                sub = synthetic.subset_table(full, Xw[0] - 12.0, Xw[-1] + 12.0)
+                oracle[i0] = np.stack([ref.layer_od(sub, Xw, a["Ts"][k], a["Ps"][k], a["PLs"][k], a["MFs_VAL"][k], a["MFs_ID"])
+                                       for k in range(32)], 1)
+            ODr = oracle[i0] * scale  # optical depth is linear in the mixing ratios (same lines, same windows)
+            tr, ur, dr = ref.tud_from_od(Xw, ODr, a["Ts"], a["Zs"])
+            sl = slice(i0, i0 + n)
+            e[0] = max(e[0], rel_err(OD[:, sl].T.double().cpu().numpy(), ODr))
+            e[1] = max(e[1], float(np.max(np.abs(tau[0, sl].double().cpu().numpy() - tr))))
+            e[2] = max(e[2], rel_err(Lu[0, sl].double().cpu().numpy(), ur))
+            e[3] = max(e[3], rel_err(Ld[sl].double().cpu().numpy(), dr))
+            spans.append(float(tr.max() - tr.min()))
+        worst[scale] = e
+        assert e[0] <= TOL_L and e[1] <= TOL_TAU and e[2] <= TOL_L and e[3] <= TOL_L, (scale, e)
+        if scale < 1.0:
+            assert max(spans) > 0.5  # the thinned column really exercises transmittances between 0 and 1
+        del OD, tau, Lu, Ld
+    print("stratified C3 sweep, worst [OD, |dtau|, Lu, Ld]:", worst)
+    lines.close()
+
+
 @pytest.mark.gpu
 def test_smooth_and_reduce_resolution_vs_golden_g9(rt, golden):
     """rt.smooth / rt.reduceResolution (rtx_fir_reflect + rtx_cubic_resample, fp64) against the
@@ -1195,6 +1244,83 @@ def test_compute_tud_batch_equals_per_call_results(rt):
         assert rel_err(g[3], rt.reduceResolution(full_res[0], full_res[3], 0.25, X_out=Xo)) <= 1e-12
 
 
+def test_compute_tud_batch_devices_and_host_paths(rt):
+    """compute_TUD_batch(devices=[0, 0]): two independent pipelines (own streams, own per-(line, layer) records, one
+    shared line table per device) dealt the atmospheres round-robin -- the reference's multiprocessing.Pool axis
+    (Generate_LWIR_TUD.py:117-150) from one process -- return, in input order, exactly what one pipeline returns;
+    out_dtype=float32 is the same numbers unwidened; a device-resident LineTable is accepted; and the zero-copy pinned
+    results of compute_TUD fall back to pageable arrays, with identical values, once the pinned cap is lent out."""
+    import torch
+    from radtxfr_amd import _hostio, engine
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    lo, hi = 1000.0, 1004.0
+    sub = synthetic.subset_table(full, lo - 12.0, hi + 12.0)
+    a = synthetic.c3_atmosphere(32)
+    a["MFs_VAL"] = a["MFs_VAL"] * 1e-3
+    rng = np.random.default_rng(5)
+    atms = [dict(Ts=a["Ts"] + rng.normal(0, 2.0, 32), MFs_VAL=a["MFs_VAL"] * rng.uniform(0.5, 1.5, (32, 1))) for _ in range(7)]
+    lines = engine.LineTable(sub)
+    common = dict(DVOUT=0.001, line_table=lines, Zs=a["Zs"], PLs=a["PLs"], MFs_ID=a["MFs_ID"], Ts=a["Ts"], Ps=a["Ps"],
+                  MFs_VAL=a["MFs_VAL"], Altitudes=np.asarray([500.0]))
+    one = rt.compute_TUD_batch(lo, hi, atms, **common)
+    two = rt.compute_TUD_batch(lo, hi, atms, devices=[0, 0], **common)
+    f32 = rt.compute_TUD_batch(lo, hi, atms, devices=[0, 0], out_dtype=np.float32, **common)
+    assert len(one) == len(two) == len(f32) == 7
+    for r1, r2, r3 in zip(one, two, f32):
+        assert r1[1].dtype == np.float64 and r3[1].dtype == np.float32 and r1[1].flags.writeable
+        for j in (1, 2, 3):
+            assert np.array_equal(r1[j], r2[j]) and np.array_equal(r1[j].astype(np.float32), r3[j])
+    assert not np.array_equal(one[0][1], one[1][1])
+    with pytest.raises(ValueError):
+        rt.compute_TUD_batch(lo, hi, atms, devices=[torch.cuda.device_count()], **common)
+    # zero-copy results are page-locked while they live; past the cap compute_TUD hands out pageable arrays
+    base = _hostio.pinned_lent_bytes()
+    r_pin = rt.compute_TUD(lo, hi, **dict(common, **atms[0]))
+    per_result = _hostio.pinned_lent_bytes() - base
+    assert per_result == 3 * r_pin[1].size * 8
+    cap0 = _hostio.PINNED_RESULT_CAP
+    try:
+        _hostio.PINNED_RESULT_CAP = _hostio.pinned_lent_bytes() + per_result // 2
+        r_page = rt.compute_TUD(lo, hi, **dict(common, **atms[0]))
+        assert _hostio.pinned_lent_bytes() == base + per_result  # nothing more was lent out
+    finally:
+        _hostio.PINNED_RESULT_CAP = cap0
+    for j in (1, 2, 3):
+        assert np.array_equal(r_pin[j], r_page[j]) and np.array_equal(r_pin[j], one[0][j])
+    del r_pin
+    import gc
+    gc.collect()
+    assert _hostio.pinned_lent_bytes() == base
+    # the axis: cached and read-only by default, a fresh writable copy on request (the reference's behaviour)
+    Xc = rt.compute_TUD(lo, hi, **dict(common, **atms[0]))[0]
+    Xw = rt.compute_TUD(lo, hi, copy_axis=True, **dict(common, **atms[0]))[0]
+    assert not Xc.flags.writeable and Xw.flags.writeable and np.array_equal(Xc, Xw) and Xw is not Xc
+    Xw *= 2.0
+    assert np.array_equal(rt.compute_TUD(lo, hi, **dict(common, **atms[0]))[0], Xc)
+    lines.close()
+
+
+def test_compute_tud_save_with_many_slants(rt, tmp_path, monkeypatch):
+    """save=True (radiative_transfer.py:374-386) with more slant paths than one rtx_tud launch takes: the slants run in
+    blocks and the per-stream downwelling radiances -- independent of the slant -- come from the first block."""
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    lo, hi = 1000.0, 1001.0
+    sub = synthetic.subset_table(full, lo - 12.0, hi + 12.0)
+    a = synthetic.c3_atmosphere(8)
+    a["MFs_VAL"] = a["MFs_VAL"] * 1e-3
+    monkeypatch.chdir(tmp_path)
+    th = np.linspace(0.0, 1.1, 10)
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, theta_r=th, save=True, N_angle=6, **a)
+    d = np.load(tmp_path / "ComputeTUD.npz")
+    assert tau.shape == (X.size, 10) and d["Ld"].shape == (X.size, 6) and d["tau"].shape == (X.size, 1, 10)
+    Xr, tau_r, Lu_r, Ld_r = ref.compute_TUD(sub, lo, hi, 0.001, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"],
+                                            theta_r=th, N_angle=6)
+    assert np.max(np.abs(tau - tau_r)) <= TOL_TAU and rel_err(Lu, Lu_r) <= TOL_L and rel_err(Ld, Ld_r) <= TOL_L
+    ang = np.linspace(0, np.pi / 2.0, 6, endpoint=False)
+    w = np.cos(ang) * np.sin(ang)
+    assert rel_err((d["Ld"] * w).sum(axis=1) / w.sum(), Ld_r) <= TOL_L
+
+
 def test_fused_entry_equals_three_calls():
     """rtx_compute_tud (engine.TudRunner: one library call per atmosphere, per-layer tables in the prologue's kernel
     arguments) gives bit-identical tau / L-up / L-down / OD to rtx_line_prep + rtx_voigt_sum + rtx_tud; also with more
@@ -1290,3 +1416,50 @@ def test_c5_full_size_sampled_pixels_vs_oracle(rt):
     xr, Lr = ref.ILS_MAKO(X, L, resFactor=2)
     assert np.array_equal(xo, xr)
     assert rel_err(cube.cpu().numpy()[:, pix], Lr) <= TOL_L
+
+
+def test_c5_full_size_end_to_end_vs_oracle(rt):
+    """Config C5 at full size, END TO END: line table + atmosphere -> dist.hsi_cube_from_atmosphere (prologue, line-sum, TUD
+    on the 570 000-point MAKO span, band moments, 256 x 256-pixel x 256-band cube). 16 sampled pixels are checked against
+    an oracle that starts from the LINE TABLE too -- oracle line-sum and oracle TUD on a 20 000-point sub-span, each
+    pixel's monochromatic spectrum, the reference's triangle ILS -- for every band whose triangle lies inside the
+    sub-span, so the sensor stage is not only checked on the engine's own tau."""
+    import torch
+    from radtxfr_amd import dist as rdist
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    lo, hi, dv = 755.0, 1325.0, 0.001
+    sub = synthetic.subset_table(full, lo - 15.0, hi + 15.0)
+    a = synthetic.c3_atmosphere(32)
+    a["MFs_VAL"] = a["MFs_VAL"] * 3e-3
+    Xe, em = synthetic.synth_emissivities(n_emis=2000)
+    sc = synthetic.synth_scene()
+    E = em[:, sc["end_idx"]].astype(np.float32)
+    dev = torch.device("cuda")
+    xo, cube = rdist.hsi_cube_from_atmosphere(lo, hi, dv, sub, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"], Xe,
+                                              torch.as_tensor(E, device=dev), torch.as_tensor(sc["kidx"], device=dev),
+                                              torch.as_tensor(sc["frac"].astype(np.float32), device=dev),
+                                              torch.as_tensor(sc["T"], device=dev), resFactor=2)
+    torch.cuda.synchronize()
+    assert cube.shape == (xo.size, 256 * 256) and xo.size >= 252 and bool(torch.isfinite(cube).all())
+    nX = int(np.ceil((hi - lo) / dv))
+    X = np.linspace(lo, hi, nX)
+    i0, n = 250000, 20000  # ~1005-1025 cm^-1
+    Xw = X[i0:i0 + n]
+    subw = synthetic.subset_table(full, Xw[0] - 12.0, Xw[-1] + 12.0)
+    ODr = np.stack([ref.layer_od(subw, Xw, a["Ts"][k], a["Ps"][k], a["PLs"][k], a["MFs_VAL"][k], a["MFs_ID"]) for k in range(32)], 1)
+    tr, ur, dr = ref.tud_from_od(Xw, ODr, a["Ts"], a["Zs"])
+    assert tr.max() - tr.min() > 0.3
+    pix = np.arange(5, 65536, 4099)[:16]
+    E_hi = np.stack([np.interp(Xw, Xe, E[:, k].astype(np.float64)) for k in range(E.shape[1])], axis=1)
+    frac = sc["frac"].astype(np.float32).astype(np.float64)[pix]
+    em_p = np.einsum("pm,xpm->xp", frac, E_hi[:, sc["kidx"][pix]])
+    Lw = tr[:, None] * (em_p * ref.planckian(Xw, sc["T"][pix]) + (1 - em_p) * dr[:, None]) + ur[:, None]
+    L_full = np.zeros((nX, pix.size))
+    L_full[i0:i0 + n] = Lw
+    xr, Lr = ref.ILS_MAKO(X, L_full, resFactor=2)
+    assert np.array_equal(xo, xr)
+    sig = np.abs(np.gradient(xr)) * 1.6
+    inside = (xr - sig > Xw[0]) & (xr + sig < Xw[-1])
+    assert inside.sum() >= 3
+    got = cube.cpu().numpy()[:, pix][inside]
+    assert rel_err(got, Lr[inside]) <= TOL_L, rel_err(got, Lr[inside])

@@ -398,3 +398,25 @@ def test_tud_downwelling_table_against_direct_sum():
         assert err.max() <= 1e-13 * g0.value, (n_angle, err.max())
         far = (direct < 1e-4 * g0.value) & (direct > 1e-14 * g0.value)   # below that nothing reaches fp32 output
         assert np.max(err[far] / direct[far]) <= 2e-8, (n_angle, np.max(err[far] / direct[far]))
+
+
+def test_column_signature_is_nan_safe_and_sees_edits():
+    """a column holding NaN (a blank field of a .par record) must not make the cached device table look stale on
+    every call, yet every in-place edit -- of a finite value, or of which rows hold NaN -- must change the fingerprint;
+    storage2cache_from_columns keeps numeric columns as ndarrays."""
+    from radtxfr_amd import hapi
+    a = np.linspace(1.0, 2.0, 1000)
+    assert hapi._column_signature(a, 1000) == hapi._column_signature(a.copy(), 1000)
+    b = a.copy()
+    b[7] = np.nan
+    s1 = hapi._column_signature(b, 1000)
+    assert s1 == hapi._column_signature(b.copy(), 1000) and s1 != hapi._column_signature(a, 1000)
+    c = b.copy()
+    c[8] *= 1.0000001
+    d = a.copy()
+    d[9] = np.nan
+    assert hapi._column_signature(c, 1000) != s1 and hapi._column_signature(d, 1000) != s1
+    hapi.storage2cache_from_columns("sigtest", {"nu": a, "molec_id": np.ones(1000, dtype=np.int64), "global_upper_quanta": ["x"] * 1000})
+    data = hapi.LOCAL_TABLE_CACHE.pop("sigtest")["data"]
+    assert isinstance(data["nu"], np.ndarray) and isinstance(data["molec_id"], np.ndarray) and isinstance(data["global_upper_quanta"], list)
+    assert data["nu"] is not a
