@@ -108,6 +108,15 @@ int rtx_line_prep(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, 
 #define RTX_PROFILE_LORENTZ 1
 #define RTX_PROFILE_DOPPLER 2
 #define RTX_PROFILE_SDVOIGT 3 /* records for rtx_sdvoigt_sum (below); windows as for Voigt */
+/* Hot tiles (line lists cluster: a band head puts thousands of candidate lines on one line-sum tile, and one workgroup per
+ * tile would serialise the launch). The prologue bounds, on the host, the candidates any tile of `grid` can have -- no
+ * window is wider than max(OmegaWing, OmegaWingHW * gamma, misc/hapi.py:11131) with the table's column extremes -- and
+ * rtx_voigt_sum cuts tiles with more than 512 candidates into parts evaluated by extra workgroups and summed in a fixed
+ * order (results stay bit-reproducible and independent of wavenumber sharding). This returns the number of extra parts
+ * the last prologue allowed for: 0 = no tile of that table / grid can be hot and the extra kernels are never launched.
+ * A bound that grows (new table or grid, much wider wings) re-allocates the part workspace inside rtx_line_prep*: the one
+ * case in which a prologue call allocates and synchronises. */
+int64_t rtx_prep_split_bound(const rtx_prep* prep);
 int rtx_line_prep_profile(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, int n_layers,
                           const double* T_h, const double* p_atm_h, const double* qratio_h,
                           const double* weight_h, const double* mass_h, double dil_air,

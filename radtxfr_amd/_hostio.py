@@ -4,11 +4,11 @@ compute_TUD_batch return float64 NumPy arrays, as the reference does, radiative_
 At C3 size one result (tau, L-up, L-down as float64) is 132 MB; the device computes it in ~2 ms, so how it reaches the
 host decides what a caller sees. Two ways, both through page-locked memory (pageable hipMemcpy is several times slower):
 
-  zero-copy   widened to float64 on the DEVICE, one asynchronous copy into pinned memory, the arrays handed out are
-              views of that pinned block (PyTorch's caching pinned allocator recycles the block when the arrays die).
-              Nothing touches the data on the host: 2.7 ms per result. A result that is KEPT keeps its block page-locked,
-              so the total lent out this way is capped (PINNED_RESULT_CAP); beyond the cap, and for batches that keep
-              every result, the second way is used.
+  zero-copy   widened to float64 on the DEVICE, one asynchronous copy into a pinned block, the arrays handed out are
+              views of that block; when they die the block returns to this module's idle list and the next result
+              reuses it. Nothing touches the data on the host: 2.7 ms per result. A result that is KEPT keeps its block
+              page-locked, so the blocks owned this way are capped (PINNED_RESULT_CAP); when all are held, and for
+              batches that keep every result, the second way is used.
   pageable    float32 crosses PCIe into a small ring of reusable pinned staging buffers (half the bytes), and a pool of
               host threads widens it into ordinary pageable arrays (NumPy releases the GIL in its copy loops; a fresh
               132 MB array costs ~35 ms of page faults and copying on one thread).
@@ -21,8 +21,10 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-PINNED_RESULT_CAP = int(os.environ.get("RADTXFR_PINNED_RESULT_BYTES", str(1 << 30)))  # pinned bytes lent out as results
-_lent = [0]
+PINNED_RESULT_CAP = int(os.environ.get("RADTXFR_PINNED_RESULT_BYTES", str(1 << 30)))  # pinned bytes owned for zero-copy results
+_lent = [0]          # bytes currently handed out
+_owned = [0]         # bytes of every block this module has page-locked (handed out + idle)
+_idle = {}           # (rows, n) -> [pinned float64 tensors] waiting for reuse
 _lent_lock = threading.Lock()
 _pool = None
 _CHUNK = 1 << 19  # elements per widening task (2-4 MB)
@@ -44,27 +46,50 @@ def pinned_lent_bytes():
     return _lent[0]
 
 
-def _release(nbytes):
+def _release(host, nbytes):
+    """A result's arrays have all died: its block goes back to the idle list (never unpinned: page-locking 132 MB costs
+    ~10 ms, and PyTorch's own pinned allocator showed 40-90 ms stalls when blocks of this size came and went)."""
     with _lent_lock:
         _lent[0] -= nbytes
+        _idle.setdefault(tuple(host.shape), []).append(host)
 
 
-def rows_to_pinned_f64(rows, stream=None):
-    """float32 device rows [(k_i, n)] -> float64 NumPy views of ONE pinned block (zero-copy path), or None when lending
-    another block would exceed PINNED_RESULT_CAP. Returns (arrays, event): valid once `event` has completed."""
-    n = rows[0].shape[-1]
-    ks = [int(np.prod(r.shape[:-1])) if r.dim() > 1 else 1 for r in rows]
-    nbytes = sum(ks) * n * 8
+def _pinned_block(shape):
+    """An idle block of this shape, or a new one while the module owns less than PINNED_RESULT_CAP; else None."""
+    nbytes = shape[0] * shape[1] * 8
     with _lent_lock:
         if _lent[0] + nbytes > PINNED_RESULT_CAP:
             return None
+        free = _idle.get(shape)
+        if free:
+            _lent[0] += nbytes
+            return free.pop()
+        # make room for a block of a new shape by dropping idle ones of other shapes
+        while _owned[0] + nbytes > PINNED_RESULT_CAP:
+            victim = next((k for k, v in _idle.items() if v), None)
+            if victim is None:
+                return None
+            t = _idle[victim].pop()
+            _owned[0] -= t.numel() * 8
+        _owned[0] += nbytes
         _lent[0] += nbytes
+    return torch.empty(shape, dtype=torch.float64, pin_memory=True)
+
+
+def rows_to_pinned_f64(rows, stream=None):
+    """float32 device rows [(k_i, n)] -> float64 NumPy views of ONE pinned block (zero-copy path), or None when every
+    block the cap allows is still held by earlier results. Returns (arrays, event): valid once `event` has completed."""
+    n = rows[0].shape[-1]
+    ks = [int(np.prod(r.shape[:-1])) if r.dim() > 1 else 1 for r in rows]
+    nbytes = sum(ks) * n * 8
+    host = _pinned_block((sum(ks), n))
+    if host is None:
+        return None
     dev_block = torch.empty((sum(ks), n), dtype=torch.float64, device=rows[0].device)
     o = 0
     for r, k in zip(rows, ks):
         dev_block[o:o + k].copy_(r.reshape(k, n))
         o += k
-    host = torch.empty((sum(ks), n), dtype=torch.float64, pin_memory=True)
     side = stream if stream is not None else torch.cuda.current_stream()
     ready = torch.cuda.Event()
     ready.record()  # the widening runs on the current (compute) stream
@@ -75,7 +100,7 @@ def rows_to_pinned_f64(rows, stream=None):
         done = torch.cuda.Event()
         done.record(side)
     arr = host.numpy()
-    weakref.finalize(arr, _release, nbytes)  # every view handed out keeps `arr` (and through it the pinned block) alive
+    weakref.finalize(arr, _release, host, nbytes)  # every view handed out keeps `arr` alive; then the block is idle again
     out, o = [], 0
     for k in ks:
         out.append(arr[o:o + k])

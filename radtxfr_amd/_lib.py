@@ -34,6 +34,7 @@ PROTOTYPES = {
     "rtx_prep_free": (_i32, [_vp]),
     "rtx_line_prep": (_i32, [_vp, _vp, _gp, _i32, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _vp]),
     "rtx_line_prep_profile": (_i32, [_vp, _vp, _gp, _i32, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _dbl, _dbl, _i32, _vp]),
+    "rtx_prep_split_bound": (_i64, [_vp]),
     "rtx_voigt_sum": (_i32, [_vp, _gp, _i32, _vp, _vp, _i64, _vp]),
     "rtx_sdvoigt_sum": (_i32, [_vp, _gp, _i32, _vp, _vp, _i64, _vp]),
     "rtx_lines_set_sd": (_i32, [_vp, _vp, _vp]),

@@ -113,6 +113,28 @@ struct rtx_lines {
   double *sd_air, *sd_self;  // optional speed-dependence columns (rtx_lines_set_sd), NULL = 0
   double* deltap_self;       // optional (rtx_lines_set_deltap_self), NULL = 0
   int* species;
+  // host side, for the bound on candidates per tile (hot-tile split, below): the sorted centres and column extremes
+  double* nu_host;
+  double ga_max, gs_max, n_lo, n_hi;
+};
+
+// ---- hot tiles ---------------------------------------------------------------------------------------
+// Real line lists cluster (band heads: thousands of lines inside a cm^-1), and one line-sum workgroup per (tile, layer)
+// then serialises the launch on its few hot tiles (the clustered synthetic table: slowest workgroup = 2x the ideal
+// duration of the whole launch, tools/tile_spread.py). A tile with more than RTX_SPLIT_PART candidates is therefore cut
+// into parts of RTX_SPLIT_PART consecutive candidates: part 0 stays with the tile's own workgroup, every further part is
+// an item of a work list (written by tile_ranges_kernel) that extra workgroups evaluate into a workspace of partial
+// tiles, and a last kernel adds a tile's parts to its optical depths in part order. The cut is a function of the
+// (canonical) candidate range alone, so results stay bit-reproducible and independent of how the axis is sharded.
+#ifndef RTX_SPLIT_PART
+#define RTX_SPLIT_PART 512
+#endif
+struct __attribute__((aligned(16))) SplitItem {
+  int tile, k;    // tile of the shard, layer
+  int lo, hi;     // candidate slots [lo, hi)
+  int part;       // 1 .. extra
+  int extra;      // number of extra parts of this (tile, layer); its items are consecutive, part 1 first
+  int pad0, pad1;
 };
 
 struct rtx_prep {
@@ -130,4 +152,14 @@ struct rtx_prep {
   double* env;         // device copy of T,p,qratio,weight,mass (packed)
   size_t env_cap;
   double scale;
+  // hot-tile split: work list and workspace sized from a HOST-side bound on the candidates per tile (no device read-back)
+  int* n_items;        // device counter (lives behind maxhw / smally: one memset per prologue)
+  SplitItem* items;    // [items_cap]
+  float* part_ws;      // [items_cap][tile points]
+  long long items_cap;
+  long long split_bound;  // extra parts the current (grid, window) bound allows for; 0 = no tile can be hot
+  double split_W;         // window half-width [cm^-1] the bound was computed for (valid for any smaller one)
+  double split_xmin, split_step;
+  long long split_off, split_n;
+  int split_layers;
 };

@@ -59,6 +59,7 @@ extern "C" int rtx_lines_free(rtx_lines* L) {
   for (double* q : p)
     if (q) (void)hipFree(q);
   if (L->species) (void)hipFree(L->species);
+  free(L->nu_host);
   delete L;
   return 0;
 }
@@ -100,9 +101,22 @@ extern "C" int rtx_lines_create(int64_t n, int n_species, const double* nu_h, co
       rc = 1;
     }
   }
+  if (!rc && n > 0) {
+    L->nu_host = (double*)malloc(sizeof(double) * (size_t)n);
+    if (!L->nu_host) { rtx_set_error("out of host memory"); rc = 1; }
+  }
   if (rc) {
     rtx_lines_free(L);
     return 1;
+  }
+  L->n_lo = 1e300; L->n_hi = -1e300;
+  for (int64_t i = 0; i < n; ++i) {
+    L->nu_host[i] = nu_h[i];
+    L->ga_max = fmax(L->ga_max, fabs(gamma_air_h[i]));
+    L->gs_max = fmax(L->gs_max, fabs(gamma_self_h[i]));
+    const double na = n_air_h[i], ns = (n_self_h && n_self_h[i] != 0.0) ? n_self_h[i] : na;
+    L->n_lo = fmin(L->n_lo, fmin(na, ns));
+    L->n_hi = fmax(L->n_hi, fmax(na, ns));
   }
   *out = L;
   return 0;
@@ -141,6 +155,8 @@ extern "C" int rtx_prep_free(rtx_prep* P) {
   if (P->env) (void)hipFree(P->env);
   if (P->ranges) (void)hipFree(P->ranges);
   if (P->recsd) (void)hipFree(P->recsd);
+  if (P->items) (void)hipFree(P->items);
+  if (P->part_ws) (void)hipFree(P->part_ws);
   delete P;
   return 0;
 }
@@ -164,8 +180,8 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
   hipError_t e = hipMalloc((void**)&P->rec, nrec * sizeof(LineRec));
   if (e == hipSuccess) e = hipMalloc((void**)&P->rec64, nrec * sizeof(LineRec64));
   if (e == hipSuccess) e = hipMalloc((void**)&P->ic, sizeof(int) * (size_t)(lines->n > 0 ? lines->n : 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&P->maxhw, 2 * sizeof(int) * (size_t)max_layers);  // [maxhw | smally]: one memset per prologue
-  if (e == hipSuccess) P->smally = P->maxhw + max_layers;
+  if (e == hipSuccess) e = hipMalloc((void**)&P->maxhw, (2 * (size_t)max_layers + 1) * sizeof(int));  // [maxhw | smally | n_items]: one memset per prologue
+  if (e == hipSuccess) { P->smally = P->maxhw + max_layers; P->n_items = P->maxhw + 2 * max_layers; }
   if (e == hipSuccess) e = hipMalloc((void**)&P->env, sizeof(double) * P->env_cap);
   if (e == hipSuccess) e = hipMalloc((void**)&P->ranges, sizeof(int2) * (size_t)P->max_tiles * (size_t)max_layers);
   if (e != hipSuccess) {
@@ -396,6 +412,67 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
   }
 }
 
+// ---- hot tiles: host-side bound on the extra parts (rtx_common.h) ------------------------------------------------------
+// No window of any line in any layer is wider than W = max(OmegaWing, HW * Gamma0_max, HW * GammaD_max) (misc/hapi.py:11131
+// with the column extremes of the table and the layer extremes of this call), and windows are centred on the UNSHIFTED
+// centres, so a tile [x_a, x_b] has at most count(nu in [x_a - W, x_b + W]) candidates: one sweep over the sorted host
+// copy of the centres. The work list and the partial-tile workspace are sized from that bound -- they cannot overflow, and
+// nothing is read back from the device. The sweep (~0.1 ms for 100 000 lines) is redone only when the grid changes or a call
+// needs a wider window than the cached bound was made for (25 % headroom). A table that cannot have a hot tile (every
+// uniform table of the benchmarks) has bound 0 and never launches the two extra kernels.
+static int rtx_split_bound(rtx_prep* P, const rtx_lines* L, const rtx_grid* g, int n_layers, const double* T_h, const double* p_h,
+                           const double* mass_h, double dil_air, double dil_self, double omega_wing, double omega_wing_hw, int profile) {
+  if (L->n == 0 || g->n == 0) { P->split_bound = 0; return 0; }
+  double g0 = 0.0, t_max = 0.0;
+  for (int k = 0; k < n_layers; ++k) {
+    const double tr = H_TREF / T_h[k];
+    g0 = fmax(g0, p_h[k] * fmax(pow(tr, L->n_lo), pow(tr, L->n_hi)));
+    t_max = fmax(t_max, T_h[k]);
+  }
+  g0 *= fabs(dil_air) * L->ga_max + fabs(dil_self) * L->gs_max;
+  double m_min = 1e300;
+  for (int s = 0; s < L->n_species; ++s)
+    if (mass_h[s] > 0.0) m_min = fmin(m_min, mass_h[s]);
+  if (!(m_min < 1e300)) m_min = 1.0;
+  const double nu_max = L->nu_host[L->n - 1];
+  double gd = sqrt(2.0 * H_CBOLTS * t_max * log(2.0) / (m_min * H_CMASSMOL * 1000.0) / (H_CC * H_CC)) * fabs(nu_max);
+  if (profile == RTX_PROFILE_DOPPLER) gd = (1.1774100225 / 2.99792458e8) * sqrt(1.3806503e-23 / 1.66053873e-27) * sqrt(t_max) * fabs(nu_max) / sqrt(m_min);
+  const double W = fmax(omega_wing, fmax(omega_wing_hw * g0, omega_wing_hw * gd)) + 2.0 * g->step;
+  const bool same_grid = P->split_xmin == g->xmin && P->split_step == g->step && P->split_off == g->offset && P->split_n == g->n;
+  if (same_grid && P->split_W > 0.0 && W <= P->split_W && n_layers <= P->split_layers) return 0;  // the cached bound covers this call
+  const double Wc = 1.25 * W;
+  const int tile = rtx_voigt_tile_points();
+  const long long n_tiles = (g->n + tile - 1) / tile;
+  long long extra = 0, a = 0, b = 0;
+  for (long long t = 0; t < n_tiles; ++t) {
+    const double xa = g->xmin + (double)(g->offset + t * tile) * g->step - Wc;
+    long long i_end = g->offset + (t + 1) * tile;
+    if (i_end > g->offset + g->n) i_end = g->offset + g->n;
+    const double xb = g->xmin + (double)i_end * g->step + Wc;
+    while (a < L->n && L->nu_host[a] < xa) ++a;
+    if (b < a) b = a;
+    while (b < L->n && L->nu_host[b] <= xb) ++b;
+    const long long cnt = b - a;
+    if (cnt > RTX_SPLIT_PART) extra += (cnt - 1) / RTX_SPLIT_PART;
+  }
+  extra *= n_layers;
+  if (extra > P->items_cap) {  // grow-only; rare (a new table / grid / much wider wings): allocates, hence synchronises
+    if (extra > 4000000LL) RTX_FAIL("hot-tile work list of %lld items: the line table is too dense for this grid", extra);
+    if (P->items) { RTX_HIP(hipFree(P->items)); P->items = nullptr; }
+    if (P->part_ws) { RTX_HIP(hipFree(P->part_ws)); P->part_ws = nullptr; }
+    P->items_cap = 0;
+    RTX_HIP(hipMalloc((void**)&P->items, (size_t)extra * sizeof(SplitItem)));
+    RTX_HIP(hipMalloc((void**)&P->part_ws, (size_t)extra * (size_t)tile * sizeof(float)));
+    P->items_cap = extra;
+  }
+  P->split_bound = extra;
+  P->split_W = Wc; P->split_xmin = g->xmin; P->split_step = g->step; P->split_off = g->offset; P->split_n = g->n;
+  P->split_layers = n_layers;
+  return 0;
+}
+
+extern "C" int64_t rtx_prep_split_bound(const rtx_prep* P) { return P ? P->split_bound : -1; }
+
 extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_grid* grid, int n_layers, const double* T_h,
                              const double* p_atm_h, const double* qratio_h, const double* weight_h, const double* mass_h,
                              double dil_air, double dil_self, double omega_wing, double omega_wing_hw,
@@ -427,7 +504,8 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
     RTX_HIP(hipMemcpyAsync(d + 2 * nT + nQ, weight_h, nQ * sizeof(double), hipMemcpyHostToDevice, st));
     RTX_HIP(hipMemcpyAsync(d + 2 * nT + 2 * nQ, mass_h, ns * sizeof(double), hipMemcpyHostToDevice, st));
   }
-  RTX_HIP(hipMemsetAsync(P->maxhw, 0, 2 * sizeof(int) * (size_t)P->max_layers, st));  // maxhw and smally
+  RTX_HIP(hipMemsetAsync(P->maxhw, 0, (2 * (size_t)P->max_layers + 1) * sizeof(int), st));  // maxhw, smally and n_items
+  if (rtx_split_bound(P, L, grid, n_layers, T_h, p_atm_h, mass_h, dil_air, dil_self, omega_wing, omega_wing_hw, profile)) return 1;
   P->n_layers = n_layers;
   P->scale = scale;
   if (L->n == 0) return 0;

@@ -16,67 +16,110 @@ struct RangeArgs {
   const int* maxhw;
   const LineRec* rec;
   long long n_lines;
-  int n_tiles, tile, n_layers;
+  int n_tiles, tile, n_layers, n_steps;
   long long n;
   int2* ranges;
+  SplitItem* items;  // hot-tile work list (rtx_common.h); NULL: no tile is cut
+  int* n_items;
+  long long items_cap;
 };
 
-// Candidate lines of tile t in layer k: unshifted-centre index within maxhw[k] of the tile.
+// Candidate lines of tile t in layer k, as a CANONICAL range [first line that reaches the tile, last such line + 1).
+// Step 1 brackets the lines whose unshifted-centre index lies within maxhw[k] of the tile (two searches on the sorted
+// centre indices); step 2 trims the bracket from both ends to the lines whose window [lo, hi) meets the tile. The bracket
+// depends on maxhw -- a maximum over whatever table the caller uploaded -- and the line-sum deals candidates to waves and
+// lanes by their position in the range, so the order of its fp32 sums would depend on it. Trimmed, the range -- hence
+// every bit of the result -- is a function of the lines that contribute to the tile and of nothing else: a rank that holds
+// only the lines in reach of its wavenumber shard reproduces the full-table, full-grid run exactly (shards cut on tile
+// boundaries: dist.py, bench.py).
+// Sixteen lanes per tile (four tiles per wave; one wave per tile was bound by the wave launch rate: 0.28 ms for 66 layers
+// x 10 742 tiles): the two searches are 17-ary -- every step probes 16 positions at once, ~5 steps for 100 000 lines
+// instead of 17 dependent loads -- and the trim scans 16 candidates' windows per step from each end.
+#define RNG_G 16
+__device__ __forceinline__ unsigned group_bits(unsigned long long b, int lane) { return (unsigned)(b >> (lane & 48)) & 0xffffu; }
+
+// number of elements of the sorted ic[lo, hi) that are < v (STRICT) or <= v, by the 16 lanes of a group. n_steps is
+// wave-uniform (host: enough for n_lines); a group that has converged early repeats a no-op.
+template <bool STRICT>
+__device__ __forceinline__ long long group_bound(const int* __restrict__ ic, long long lo, long long hi, long long v, int sub, int lane,
+                                                 int n_steps) {
+  for (int it = 0; it < n_steps; ++it) {
+    const long long width = hi - lo;
+    const long long stride = (width + RNG_G) / (RNG_G + 1);  // >= 1 while width > 0
+    const long long p = lo + (long long)(sub + 1) * stride - 1;
+    const bool pred = width > 0 && p < hi && (STRICT ? (long long)ic[p] < v : (long long)ic[p] <= v);
+    const int c = __popc(group_bits(__ballot(pred), lane));  // the predicate is monotone along the probes
+    if (width > 0) {
+      // probe c was evaluated and failed when it lies inside the bracket: the answer is <= its position
+      const long long cap = lo + (long long)(c + 1) * stride - 1;
+      if (c < RNG_G && cap < hi) hi = cap;
+      lo += (long long)c * stride;  // probes 0 .. c-1 passed: the answer is > their positions
+    }
+  }
+  return lo;
+}
+
 __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, sub = lane & (RNG_G - 1);
+  const int t = (int)((blockIdx.x * blockDim.x + threadIdx.x) / RNG_G);
   const int k = blockIdx.y;
-  if (t >= a.n_tiles) return;
+  const bool live = t < a.n_tiles;  // dead groups run along (the ballots are wave-wide) on an empty bracket
   const long long ia = (long long)t * a.tile;
   long long ib = ia + a.tile;
   if (ib > a.n) ib = a.n;
   const long long hw = a.maxhw[k];
-  const long long vlo = ia - hw, vhi = ib - 1 + hw;
-  long long lo = 0, hi = a.n_lines;  // lower_bound(ic, vlo)
-  while (lo < hi) {
-    long long mid = (lo + hi) >> 1;
-    if ((long long)a.ic[mid] < vlo) lo = mid + 1; else hi = mid;
-  }
-  const long long l0 = lo;
-  hi = a.n_lines;  // upper_bound(ic, vhi), starting from l0
-  while (lo < hi) {
-    long long mid = (lo + hi) >> 1;
-    if ((long long)a.ic[mid] <= vhi) lo = mid + 1; else hi = mid;
-  }
-  a.ranges[(size_t)k * a.n_tiles + t] = make_int2((int)l0, (int)lo);
-}
-
-// Canonical ranges: [first line that REACHES the tile, last such line + 1). The bracket above depends on maxhw -- a maximum
-// over whatever table the caller uploaded -- and the line-sum deals candidates to waves and lanes by their position in the
-// range, so the order of its fp32 sums would depend on the bracket. Trimmed to the reaching lines, the range -- hence every
-// bit of the result -- is a function of the lines that contribute to the tile and of nothing else: a rank that holds only
-// the lines in reach of its wavenumber shard reproduces the full-table, full-grid run exactly (shards cut on tile
-// boundaries; dist.py, bench.py). One wave per (tile, layer): 64 candidates' windows per step, from each end.
-__global__ __launch_bounds__(256) void tile_trim_kernel(RangeArgs a) {
-  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-  const int k = blockIdx.y;
-  if (wave >= a.n_tiles) return;
-  const long long ia = (long long)wave * a.tile;
-  long long ib = ia + a.tile;
-  if (ib > a.n) ib = a.n;
-  const size_t o = (size_t)k * a.n_tiles + wave;
-  const int2 rng = a.ranges[o];
+  const long long l0 = group_bound<true>(a.ic, 0, live ? a.n_lines : 0, ia - hw, sub, lane, a.n_steps);
+  const long long l1 = group_bound<false>(a.ic, l0, live ? a.n_lines : 0, ib - 1 + hw, sub, lane, a.n_steps);
   const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
-  int first = rng.y, last = rng.y;  // nothing reaches: empty range
-  for (int base = rng.x; base < rng.y; base += 64) {
-    const int s = base + lane;
-    const bool reach = s < rng.y && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
-    const unsigned long long m = __ballot(reach);
-    if (m) { first = base + __builtin_ctzll(m); break; }
-  }
-  if (first < rng.y) {
-    for (int top = rng.y; top > first; top -= 64) {
-      const int s = top - 1 - lane;
-      const bool reach = s >= first && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
-      const unsigned long long m = __ballot(reach);
-      if (m) { last = top - __builtin_ctzll(m); break; }
+  long long first = l1, last = l1;  // nothing reaches: empty range
+  {
+    long long base = l0;
+    bool done = base >= l1;
+    while (__ballot(!done)) {
+      const long long s = base + sub;
+      const bool reach = !done && s < l1 && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
+      const unsigned m = group_bits(__ballot(reach), lane);
+      if (!done) {
+        if (m) { first = base + __builtin_ctz(m); done = true; }
+        else { base += RNG_G; done = base >= l1; }
+      }
     }
   }
-  if (lane == 0) a.ranges[o] = make_int2(first, last);
+  if (first < l1) {
+    long long top = l1;
+    bool done = false;
+    while (__ballot(!done)) {
+      const long long s = top - 1 - sub;
+      const bool reach = !done && s >= first && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
+      const unsigned m = group_bits(__ballot(reach), lane);
+      if (!done) {
+        if (m) { last = top - __builtin_ctz(m); done = true; }
+        else { top -= RNG_G; done = top <= first; }  // cannot happen before `first` itself is met
+      }
+    }
+  }
+  if (live && sub == 0) {
+    // a hot tile keeps its first RTX_SPLIT_PART candidates; every further part becomes an item of the work list (consecutive
+    // slots, part 1 first). The list is sized from a host-side bound (rtx_split_bound) and cannot overflow; should it ever,
+    // the tile is simply left whole.
+    const long long cnt = last - first;
+    if (a.items && cnt > RTX_SPLIT_PART) {
+      const int extra = (int)((cnt - 1) / RTX_SPLIT_PART);
+      const long long at = (long long)atomicAdd(a.n_items, extra);
+      if (at + extra <= a.items_cap) {
+        for (int p = 1; p <= extra; ++p) {
+          SplitItem it;
+          it.tile = t; it.k = k; it.part = p; it.extra = extra; it.pad0 = it.pad1 = 0;
+          it.lo = (int)(first + (long long)p * RTX_SPLIT_PART);
+          const long long e = first + (long long)(p + 1) * RTX_SPLIT_PART;
+          it.hi = (int)(e < last ? e : last);
+          a.items[at + p - 1] = it;
+        }
+        last = first + RTX_SPLIT_PART;
+      }
+    }
+    a.ranges[(size_t)k * a.n_tiles + t] = make_int2((int)first, (int)last);
+  }
 }
 
 int rtx_voigt_scatter_tile_points(void);
@@ -86,15 +129,19 @@ extern "C" int rtx_voigt_tile_points(void) { return rtx_voigt_scatter_tile_point
 
 // rtx_voigt_scatter.hip
 int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64, int64_t ld,
-                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t),
+                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t, int),
                           int nodal);
 
-static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_layers, int n_tiles, int tile, hipStream_t st) {
+static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_layers, int n_tiles, int tile, hipStream_t st, int split) {
   RangeArgs ra;
+  const bool cut = split && P->split_bound > 0 && P->items;
+  ra.items = cut ? P->items : nullptr; ra.n_items = P->n_items; ra.items_cap = P->items_cap;
   ra.ic = P->ic; ra.maxhw = P->maxhw; ra.rec = P->rec; ra.n_lines = P->n_lines; ra.n_tiles = n_tiles; ra.tile = tile;
   ra.n_layers = n_layers; ra.n = grid->n; ra.ranges = P->ranges;
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles + 255) / 256, n_layers), dim3(256), 0, st, ra);
-  hipLaunchKernelGGL(tile_trim_kernel, dim3((n_tiles + 3) / 4, n_layers), dim3(256), 0, st, ra);
+  int n_steps = 2;  // 17-ary search: each step divides the bracket by 17; two more to finish the last <= 17 elements
+  for (long long w = P->n_lines; w > 0; w /= (RNG_G + 1)) ++n_steps;
+  ra.n_steps = n_steps;
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles * RNG_G + 255) / 256, n_layers), dim3(256), 0, st, ra);
 }
 
 // RADTXFR_VOIGT_KERNEL=scatter selects the point-by-point cross-check kernel instead of the default nodal one.

@@ -75,6 +75,10 @@ struct ScArgs {
   double* out64;
   long long ld;
   double inv_scale;
+  // hot-tile split (rtx_common.h): the work list of extra parts and the workspace of their partial tiles
+  const SplitItem* items;
+  const int* n_items;
+  float* part_ws;
 };
 
 // Row geometry of one line in one tile, in plain integer arithmetic so that the scalar per-line code and the
@@ -417,8 +421,11 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #endif
 // SMALLY: the instantiation for layers that hold Doppler-dominated (y < 1) lines: their band lanes take the fp64 Weideman
 // value right here (band_row MODE 2) instead of in a second pass over the layer.
+// part_out == nullptr: the tile of workgroup slot b, candidates = its (possibly cut) range, result stored to the optical
+// depths. part_out != nullptr: an extra part of a hot tile -- tile b_or_tile, candidates part_rng -- stored to part_out[0 .. TILE).
 template <bool SMALLY>
-__device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const int k) {
+__device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile, const int k, const int2 part_rng = make_int2(0, 0),
+                                           float* __restrict__ part_out = nullptr) {
   constexpr int ROWS = RTX_SC_ROWS;
   constexpr int TILE = 64 * ROWS;
   __shared__ float s_acc[SC_NW][TILE];              // one private tile per wave (near rows)
@@ -428,7 +435,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const i
   // after the last drain the entry lists are dead: wave w keeps its row-level sums [ROWS][8] in its list
   static_assert(RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "row sums fit in one wave's entry list");
 
-  const int tile = xcd_tile(b);  // XCD-aware order (rtx_common.h)
+  const int tile = part_out ? b_or_tile : xcd_tile(b_or_tile);  // XCD-aware order (rtx_common.h)
   if (tile >= a.n_tiles) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -438,7 +445,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const i
   const int nt = ib - ia;
   const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
   const LineRec64* __restrict__ rec64 = a.rec64 + (size_t)k * (size_t)a.n_lines;
-  const int2 rng = a.ranges[(size_t)k * a.n_tiles + tile];
+  const int2 rng = part_out ? part_rng : a.ranges[(size_t)k * a.n_tiles + tile];
   float* __restrict__ acc = s_acc[wave];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r * 64 + lane] = 0.f;
@@ -719,14 +726,16 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b, const i
       if constexpr (SC_NW >= 2) pp += s_acc[1][t];
       if constexpr (SC_NW == 4) pp += s_acc[2][t] + s_acc[3][t];
       const float v = pp + f;
-      if (i < (long long)ib) {
+      if (part_out) {
+        part_out[t] = v;  // a partial tile: added to the optical depths by split_combine_kernel, in part order
+      } else if (i < (long long)ib) {
         const size_t o = (size_t)k * (size_t)a.ld + (size_t)i;
         if (a.out32) a.out32[o] = v;
         if (a.out64) a.out64[o] = (double)v * a.inv_scale;
       }
     }
   }
-  if (RTX_SC_STAMP) {
+  if (RTX_SC_STAMP && !part_out) {
     t_ph[7] = (long long)clock64() - t_begin;  // lifetime (includes the final stages, which have no bucket of their own)
     if (lane == 0) {
       unsigned long long* o = a.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * SC_NW + wave) * SC_NSTAMP;
@@ -756,16 +765,52 @@ __global__ __launch_bounds__(64 * SC_NW, SMALLY ? RTX_SC_WAVES_SMALLY : RTX_SC_W
   }
 }
 
+// Extra parts of hot tiles: workgroup i evaluates item i of the work list into its partial tile. Launched with the
+// list's CAPACITY (the host-side bound); workgroups beyond the count written by tile_ranges_kernel return at once.
+template <bool SMALLY>
+__global__ __launch_bounds__(64 * SC_NW, SMALLY ? RTX_SC_WAVES_SMALLY : RTX_SC_WAVES) void voigt_nodal_parts_kernel(ScArgs a) {
+  const int i = blockIdx.x;
+  if (i >= *a.n_items) return;
+  const SplitItem it = a.items[i];
+  if ((a.smally[it.k] != 0) != SMALLY) return;
+  nodal_tile<SMALLY>(a, it.tile, it.k, make_int2(it.lo, it.hi), a.part_ws + (size_t)i * (size_t)(64 * RTX_SC_ROWS));
+}
+
+// optical depths of a hot tile = part 0 (stored by the tile's own workgroup) + part 1 + part 2 + ..., added in that order by
+// the workgroup of the tile's part-1 item (its items are consecutive in the list).
+__global__ __launch_bounds__(256) void split_combine_kernel(ScArgs a) {
+  constexpr int TILE = 64 * RTX_SC_ROWS;
+  const int i = blockIdx.x;
+  if (i >= *a.n_items) return;
+  const SplitItem it = a.items[i];
+  if (it.part != 1) return;
+  const long long ia = (long long)it.tile * TILE;
+  for (int t = threadIdx.x; t < TILE; t += 256) {
+    const long long p = ia + t;
+    if (p >= a.g.n) break;
+    const size_t o = (size_t)it.k * (size_t)a.ld + (size_t)p;
+    float v = a.out32 ? a.out32[o] : 0.f;
+    double v64 = a.out64 ? a.out64[o] : 0.0;
+    for (int e = 0; e < it.extra; ++e) {
+      const float w = a.part_ws[(size_t)(i + e) * TILE + t];
+      v += w;
+      v64 += (double)w * a.inv_scale;
+    }
+    if (a.out32) a.out32[o] = v;
+    if (a.out64) a.out64[o] = v64;
+  }
+}
+
 __attribute__((visibility("hidden"))) int rtx_voigt_scatter_tile_points(void) { return 64 * RTX_SC_ROWS; }
 
 int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers, float* out_f32, double* out_f64, int64_t ld,
-                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t),
+                          hipStream_t st, void (*launch_ranges)(const rtx_prep*, const rtx_grid*, int, int, int, hipStream_t, int),
                           int nodal) {
   constexpr int TILE = 64 * RTX_SC_ROWS;
   const long long n_tiles_ll = (grid->n + TILE - 1) / TILE;
   if (n_tiles_ll > P->max_tiles) RTX_FAIL("grid shard of %lld points exceeds the prep capacity", (long long)grid->n);
   const int n_tiles = (int)n_tiles_ll;
-  launch_ranges(P, grid, n_layers, n_tiles, TILE, st);
+  launch_ranges(P, grid, n_layers, n_tiles, TILE, st, nodal);  // the point-by-point cross-check takes every tile whole
   RTX_LAUNCH_CHECK();
   ScArgs a;
   a.rec = P->rec; a.rec64 = P->rec64; a.ranges = P->ranges; a.smally = P->smally; a.n_lines = P->n_lines;
@@ -773,6 +818,7 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   a.g = to_dev(grid);
   a.out32 = out_f32; a.out64 = out_f64; a.ld = ld; a.inv_scale = 1.0 / P->scale;
   a.stamp = nullptr;
+  a.items = P->items; a.n_items = P->n_items; a.part_ws = P->part_ws;
 #if RTX_SC_STAMP
   static unsigned long long* d_stamp = nullptr;
   static size_t stamp_cap = 0;
@@ -792,6 +838,13 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
     hipLaunchKernelGGL((voigt_nodal_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(64 * SC_NW), (size_t)lds_pad, st, a);
     RTX_LAUNCH_CHECK();
     hipLaunchKernelGGL((voigt_nodal_kernel<true>), dim3(8 * ((a.tiles_per_xcd + 15) / 16), n_layers), dim3(64 * SC_NW), 0, st, a);
+    if (P->split_bound > 0 && P->items) {  // the table can have hot tiles: their extra parts, then the sums in part order
+      RTX_LAUNCH_CHECK();
+      const unsigned cap = (unsigned)P->split_bound;
+      hipLaunchKernelGGL((voigt_nodal_parts_kernel<false>), dim3(cap), dim3(64 * SC_NW), 0, st, a);
+      hipLaunchKernelGGL((voigt_nodal_parts_kernel<true>), dim3(cap), dim3(64 * SC_NW), 0, st, a);
+      hipLaunchKernelGGL(split_combine_kernel, dim3(cap), dim3(256), 0, st, a);
+    }
   } else {
     hipLaunchKernelGGL((voigt_scatter_kernel<false>), dim3(8 * a.tiles_per_xcd, n_layers), dim3(256), 0, st, a);
   }

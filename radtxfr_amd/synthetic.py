@@ -46,6 +46,71 @@ def synth_line_table(seed, n_lines, nu_lo, nu_hi):
     }
 
 
+def synth_clustered_table(seed, n_lines, nu_lo, nu_hi, n_heads=12, head_lines=3000, head_width=0.5):
+    """A line table shaped like real line lists rather than like uniform noise (H2O / CO2 lists cluster: Q-branches with
+    hundreds of lines per cm^-1, repeated centres, combs, empty windows between bands). Same columns, distributions of
+    the line parameters and `.par` rounding as synth_line_table; what differs is WHERE the lines sit:
+      * n_heads band heads: head_lines lines inside head_width cm^-1, their centres drawn from ~head_lines/4 distinct
+        values (so identical nu occur, as blended lines do), strengths spanning the whole 1e-30 ... 1e-19 in one tile;
+      * a P/R comb beside every head: spacing ~ 2B(1 -/+ J/J_max) shrinking towards the head, B ~ 0.4 ... 1.9 cm^-1;
+      * the remainder uniform over 40 % of the span only, so whole stretches hold no line or one isolated line.
+    Sorted by nu. The reference's per-line loop (misc/hapi.py:11050) has no notion of tiles; this is the table that makes
+    a tiled engine show whether a hot tile serialises a launch."""
+    rng = np.random.default_rng(seed)
+    span = nu_hi - nu_lo
+    heads = np.sort(rng.uniform(nu_lo + 0.05 * span, nu_hi - 0.05 * span, n_heads))
+    parts = []
+    for h in heads:
+        distinct = h + rng.uniform(0.0, head_width, max(1, head_lines // 4))
+        parts.append(rng.choice(distinct, head_lines))
+    n_left = n_lines - n_heads * head_lines
+    assert n_left > 0, "n_lines too small for the band heads"
+    n_comb = n_left // 2
+    per = n_comb // (2 * n_heads)
+    for h in heads:
+        B = rng.uniform(0.4, 1.9)
+        J = np.arange(1, per + 1)
+        d = np.cumsum(2.0 * B * np.maximum(0.02, 1.0 - J / (1.15 * per)) * 40.0 / per)  # ~40 cm^-1 per branch
+        parts.append(h - d)
+        parts.append(h + head_width + d)
+    n_iso = n_lines - sum(p.size for p in parts)
+    # isolated / sparse remainder: uniform over random sub-intervals covering 40 % of the span
+    edges = np.sort(rng.uniform(nu_lo, nu_hi, 40))
+    keep = rng.random(edges.size - 1) < 0.4
+    keep[0] = True
+    seg_lo, seg_hi = edges[:-1][keep], edges[1:][keep]
+    w = (seg_hi - seg_lo) / (seg_hi - seg_lo).sum()
+    # one isolated line in the middle of every dropped stretch (those away from a comb have no neighbour for tens of cm^-1)
+    mid = 0.5 * (edges[:-1][~keep] + edges[1:][~keep])
+    parts.append(mid)
+    n_iso -= mid.size
+    seg = rng.choice(seg_lo.size, n_iso, p=w)
+    parts.append(seg_lo[seg] + rng.random(n_iso) * (seg_hi - seg_lo)[seg])
+    nu = np.clip(np.concatenate(parts), nu_lo, nu_hi)
+    n = nu.size
+    molec = rng.integers(1, 3, n)
+    iso = np.where(rng.random(n) < 0.9, 1, 2)
+    sw = 10.0 ** rng.uniform(-30.0, -19.0, n)
+    elower = rng.uniform(0.0, 3000.0, n)
+    gamma_air = rng.uniform(0.03, 0.11, n)
+    gamma_self = rng.uniform(0.1, 0.5, n)
+    n_air = rng.uniform(0.4, 0.8, n)
+    delta_air = rng.uniform(-0.01, 0.002, n)
+    order = np.argsort(np.round(nu, 6), kind="stable")
+    f = lambda v: v[order]
+    return {
+        "molec_id": f(molec.astype(np.int64)),
+        "local_iso_id": f(iso.astype(np.int64)),
+        "nu": f(np.round(nu, 6)),
+        "sw": f(np.array([float("%10.3E" % v) for v in sw])),
+        "elower": f(np.round(elower, 4)),
+        "gamma_air": f(np.round(gamma_air, 4)),
+        "gamma_self": f(np.round(gamma_self, 3)),
+        "n_air": f(np.round(n_air, 2)),
+        "delta_air": f(np.round(delta_air, 6)),
+    }
+
+
 def subset_table(tbl, lo, hi):
     """Rows with lo <= nu <= hi (a line farther than its wing cutoff cannot contribute)."""
     m = (tbl["nu"] >= lo) & (tbl["nu"] <= hi)

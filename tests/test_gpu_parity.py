@@ -131,6 +131,100 @@ def test_voigt_window_edges_exact(hapi):
             assert rel_err(xs, xr) <= TOL_L
 
 
+def _clustered():
+    tbl = synthetic.synth_clustered_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    h, edges = np.histogram(tbl["nu"], bins=np.arange(475.0, 6026.0, 0.5))
+    return tbl, edges, h
+
+
+def test_clustered_table_band_head_vs_oracle(hapi):
+    """A line list shaped like HITRAN rather than uniform noise: a band head with 3000 lines inside
+    0.5 cm^-1 -- a quarter of them distinct centres, the rest exact repeats -- strengths spanning 1e-30 ... 1e-19 within one
+    tile, a P/R comb on both sides: thousands of candidates per tile, many identical nearest-grid indices. Against the
+    oracle at 0.001 and 0.0005 cm^-1, at the surface and at 0.01 atm (Doppler-dominated: the fp64 band lanes); plus an
+    isolated line in an otherwise empty span (most tiles of its window hold nothing else)."""
+    tbl, edges, h = _clustered()
+    head = float(edges[int(np.argmax(h))])
+    assert h.max() >= 2500
+    for step in (0.001, 0.0005):
+        grid = np.linspace(head - 1.0, head + 1.5, int(round(2.5 / step)) + 1)
+        sub = synthetic.subset_table(tbl, grid[0] - 12.0, grid[-1] + 12.0)
+        assert sub["nu"].size > 3000 and np.unique(sub["nu"]).size < sub["nu"].size - 1000
+        hapi.storage2cache_from_columns("clu", sub)
+        for T, p in ((287.9, 0.994), (220.0, 0.01)):
+            _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="clu", Environment={"T": T, "p": p}, OmegaGrid=grid)
+            _, xr = ref.absorptionCoefficient_Voigt(sub, T=T, p=p, OmegaGrid=grid)
+            assert xr.max() > 100 * np.median(xr) or xr.min() > 0
+            assert rel_err(xs, xr) <= TOL_L, (step, T, p, rel_err(xs, xr))
+    # an isolated line: the emptiest 20 cm^-1 around a line centre
+    nu = tbl["nu"]
+    gap = np.minimum(np.diff(nu)[1:], np.diff(nu)[:-1])  # distance to the nearer neighbour, for lines 1 .. n-2
+    r = int(np.argmax(gap)) + 1
+    assert gap[r - 1] > 3.0
+    grid = np.linspace(nu[r] - 6.0, nu[r] + 6.0, 12001)
+    sub = synthetic.subset_table(tbl, grid[0] - 12.0, grid[-1] + 12.0)
+    hapi.storage2cache_from_columns("clu", sub)
+    _, xs = hapi.absorptionCoefficient_Voigt(SourceTables="clu", Environment={"T": 287.9, "p": 0.994}, OmegaGrid=grid)
+    _, xr = ref.absorptionCoefficient_Voigt(sub, T=287.9, p=0.994, OmegaGrid=grid)
+    assert np.array_equal(xs != 0, xr != 0) and (xr == 0).sum() > 100 and rel_err(xs, xr) <= TOL_L
+    hapi.LOCAL_TABLE_CACHE.pop("clu")
+
+
+def test_clustered_table_full_grid_properties():
+    """The clustered table on the FULL C3 grid x 32 layers: optical depth of every layer against the oracle on windows at a
+    band head, on its comb and in an empty stretch; the same bits from run to run; and a tile-aligned shard computed from
+    only the lines in reach of it (what a rank of N holds) bit-identical to the same slice of the full-table, full-grid
+    run -- the candidate ranges are trimmed to the lines that reach each tile, so neither the table subset nor a hot
+    tile's thousands of candidates change the order of the sums."""
+    import torch
+    from radtxfr_amd import _lib, engine
+    tbl, edges, h = _clustered()
+    a = synthetic.c3_atmosphere(32)
+    lines = engine.LineTable(tbl)
+    grid = engine.Grid(500.0, 6000.0, 5500000)
+    OD = engine.optical_depths(lines, grid, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(OD).all()) and float(OD.min()) >= 0.0
+    # the band heads put > 512 candidates on some tiles: those are cut into parts (rtx_prep_split_bound > 0); the uniform
+    # benchmark table has no such tile and never launches the extra kernels
+    lib = _lib.load()
+    assert lib.rtx_prep_split_bound(lines.plan(32, grid.n)._h) > 100
+    OD_b = engine.optical_depths(lines, grid, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    assert torch.equal(OD, OD_b), "not bit-reproducible from run to run"
+    uni = engine.LineTable(synthetic.subset_table(synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0), 900.0, 1100.0))
+    g_u = engine.Grid(500.0, 6000.0, 5500000).shard(450 * 1024, 64 * 1024)
+    engine.optical_depths(uni, g_u, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    assert lib.rtx_prep_split_bound(uni.plan(32, g_u.n)._h) == 0
+    uni.close()
+    del OD_b
+    X = grid.axis()
+    inside = (edges[:-1] > 520.0) & (edges[:-1] < 5980.0)
+    head = float(edges[:-1][inside][int(np.argmax(h[inside]))])
+    empty = float(edges[:-1][inside][int(np.argmin(h[inside]))])
+    for x0, n in ((head - 0.2, 900), (head + 6.0, 900), (empty, 900)):
+        i0 = int((x0 - 500.0) / grid.step)
+        Xw = X[i0:i0 + n]
+        sub = synthetic.subset_table(tbl, Xw[0] - 12.0, Xw[-1] + 12.0)
+        ODr = np.stack([ref.layer_od(sub, Xw, a["Ts"][k], a["Ps"][k], a["PLs"][k], a["MFs_VAL"][k], a["MFs_ID"]) for k in range(32)], 1)
+        got = OD[:, i0:i0 + n].T.double().cpu().numpy()
+        if ODr.max() == 0.0:
+            assert got.max() == 0.0
+        else:
+            assert rel_err(got, ODr) <= TOL_L, (x0, rel_err(got, ODr))
+    # a rank's view: tile-aligned shard around the head, only the lines in reach
+    tp = int(_lib.load().rtx_voigt_tile_points())
+    t0 = int((head - 500.0) / grid.step) // tp - 3
+    sh = grid.shard(t0 * tp, 9 * tp)
+    reach = engine.max_wing_cm(tbl, a["Ts"], a["Ps"] / 101325.0) + grid.step
+    sub = synthetic.subset_table(tbl, sh.x_at(0) - reach, sh.x_at(sh.n - 1) + reach)
+    assert 3000 < sub["nu"].size < 20000
+    lines_s = engine.LineTable(sub)
+    OD_s = engine.optical_depths(lines_s, sh, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    assert torch.equal(OD_s, OD[:, sh.offset:sh.offset + sh.n]), "a rank's shard (subset table) differs from the full run"
+    lines_s.close()
+    lines.close()
+
+
 def test_voigt_doppler_regime_vs_oracle(hapi):
     """Low pressure / high wavenumber: y << 1, most of the window inside the Weideman region."""
     tbl = synthetic.synth_line_table(5, 300, 4990.0, 5010.0)

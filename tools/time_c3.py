@@ -14,9 +14,10 @@ ap.add_argument("--layers", type=int, default=32)
 ap.add_argument("--n-alt", type=int, default=1, help="sensor altitudes (the reference's main caller asks for 9)")
 ap.add_argument("--shard", type=str, default="", help="R/N: time rank R's wavenumber shard of N, with the FULL line table")
 ap.add_argument("--mf-scale", type=float, default=1.0, help="scale the mixing ratios (1e-4: an optically thin column, tau ~ 0.5-1 between lines)")
+ap.add_argument("--table", default="uniform", choices=["uniform", "clustered"], help="clustered: band heads of 3000 lines per 0.5 cm^-1, combs, empty stretches (synthetic.synth_clustered_table)")
 args = ap.parse_args()
 lib = _lib.load()
-full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+full = (synthetic.synth_clustered_table if args.table == "clustered" else synthetic.synth_line_table)(synthetic.SEED_C3, 100000, 475.0, 6025.0)
 A = synthetic.load_standard_atmosphere()[:args.layers]
 atm = dict(Zs=A[:, 1], Ts=A[:, 5], Ps=A[:, 4], PLs=A[:, 3], MFs_VAL=A[:, 6:8] * 1e6 * args.mf_scale, MFs_ID=np.array([1, 2]))
 lines = engine.LineTable(full)

@@ -9,6 +9,18 @@ import torch
 from radtxfr_amd import engine, synthetic
 from radtxfr_amd import radiative_transfer as rt
 
+import gc
+slow_gc, _gc_t = [], [0.0]
+
+
+def _gc_cb(phase, info):  # an unexplained 79 ms call in round 2's record: log every collection that takes more than 1 ms
+    if phase == "start":
+        _gc_t[0] = time.perf_counter()
+    elif (time.perf_counter() - _gc_t[0]) > 1e-3:
+        slow_gc.append((time.perf_counter() - _gc_t[0]) * 1e3)
+
+
+gc.callbacks.append(_gc_cb)
 ap = argparse.ArgumentParser()
 ap.add_argument("--mf-scale", type=float, default=1.0)
 ap.add_argument("--batch", type=int, default=8)
@@ -36,15 +48,61 @@ for it in range(6):
     ts.append((time.perf_counter() - t0) * 1e3)
     del X, tau, Lu, Ld
 print("  ... with line_table = column dict, per call [ms]:", " ".join("%.1f" % t for t in ts), "-> median of the last 4: %.1f ms" % np.median(ts[2:]))
+# ... and as a named table of the hapi cache (storage2cache_from_columns: numeric columns kept as ndarrays)
+from radtxfr_amd import hapi
+hapi.storage2cache_from_columns("dropin", full)
+kw_n = dict(kw, line_table="dropin")
+ts = []
+for it in range(6):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    X, tau, Lu, Ld = rt.compute_TUD(500.0, 6000.0, **kw_n)
+    ts.append((time.perf_counter() - t0) * 1e3)
+    del X, tau, Lu, Ld
+print("  ... with line_table = name of a cached table, per call [ms]:", " ".join("%.1f" % t for t in ts), "-> median of the last 4: %.1f ms" % np.median(ts[2:]))
+# a caller that KEEPS its results: the pinned zero-copy blocks are capped, later results land in pageable memory
+keep, ts = [], []
+from radtxfr_amd import _hostio
+for it in range(12):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    keep.append(rt.compute_TUD(500.0, 6000.0, **kw))
+    ts.append((time.perf_counter() - t0) * 1e3)
+print("  ... results kept by the caller, per call [ms]:", " ".join("%.1f" % t for t in ts), "; pinned bytes lent out: %.0f MB of a %.0f MB cap"
+      % (_hostio.pinned_lent_bytes() / 1e6, _hostio.PINNED_RESULT_CAP / 1e6))
+del keep
+gc.collect()
+# the pieces of the pageable path on their own: float32 device rows -> pinned ring (PCIe), pinned -> fresh pageable float64
+dev_rows = [torch.rand((1, 5500000), dtype=torch.float32, device="cuda") for _ in range(3)]
+st = _hostio.Staging(depth=2)
+t_dma, t_wid = [], []
+for it in range(6):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tk = st.stage(dev_rows)
+    tk[3].synchronize()
+    t1 = time.perf_counter()
+    out = st.collect(tk)
+    t2 = time.perf_counter()
+    t_dma.append((t1 - t0) * 1e3)
+    t_wid.append((t2 - t1) * 1e3)
+print("pageable path, one C3 result: 66 MB float32 over PCIe into the pinned ring %.2f ms (%.1f GB/s); widening into fresh pageable float64 "
+      "(132 MB, %d host threads) %.2f ms" % (np.median(t_dma[2:]), 66.0 / np.median(t_dma[2:]), _hostio._threads()._max_workers, np.median(t_wid[2:])))
+del dev_rows, out
 rng = np.random.default_rng(0)
 atms = [dict(Ts=a["Ts"] + rng.normal(0, 1.0, 32)) for _ in range(args.batch)]
-for label, red in (("full spectra", None), ("reduceResolution dX=0.25 on the device", dict(dX=0.25))):
+for label, extra in (("full spectra, float64", dict()), ("full spectra, float32 out", dict(out_dtype=np.float32)),
+                     ("full spectra, float64, devices=[0, 0]", dict(devices=[0, 0])),
+                     ("reduceResolution dX=0.25 on the device", dict(reduce=dict(dX=0.25))),
+                     ("reduceResolution dX=0.25, devices=[0, 0]", dict(reduce=dict(dX=0.25), devices=[0, 0]))):
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = rt.compute_TUD_batch(500.0, 6000.0, atms, reduce=red, **kw)
+        res = rt.compute_TUD_batch(500.0, 6000.0, atms, **extra, **kw)
         dt = (time.perf_counter() - t0) * 1e3
     print(f"rt.compute_TUD_batch, {args.batch} atmospheres, {label}: {dt / args.batch:.2f} ms per atmosphere "
           f"({5.5e6 * 32 * args.batch / dt / 1e-3:.3e} points/s), output points per spectrum {res[0][0].size}")
     del res
+if slow_gc:
+    print("garbage collections longer than 1 ms during this run [ms]:", " ".join("%.1f" % t for t in slow_gc))
 lines.close()
