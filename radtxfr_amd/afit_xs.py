@@ -15,7 +15,7 @@ import struct
 import numpy as np
 import torch
 
-from . import engine
+from . import _lib, engine
 from . import hapi as _hapi
 
 _HEADER = struct.Struct("<2s6d128s")
@@ -68,18 +68,29 @@ def cross_section_grid(SourceTables, T, P_atm, X, WavenumberWingHW=50.0, Wavenum
     scale = 2.0 ** (-np.floor(np.log2(smax))) if smax > 0 and np.isfinite(smax) else 1.0
     dil = {"air": 1.0} if GammaL.lower() == "gamma_air" else {"self": 1.0}
     out = np.empty((len(states), X.size))
-    for s0 in range(0, len(states), 128):
-        chunk = states[s0:s0 + 128]
+    # states per launch: the per-(line, state) records (80-128 B each) and, with the caller's 350-half-width wings, the
+    # partial tiles of the line-sum's part list (every tile then has > 256 candidate lines) must fit comfortably
+    per = max(1, min(128, int(2.0e9 / (128.0 * max(tbl.n, 1)))))
+    s0 = 0
+    while s0 < len(states):
+        chunk = states[s0:s0 + per]
         Tk = np.array([c[0] for c in chunk])
         pk = np.array([c[1] for c in chunk])
-        dev = torch.empty((len(chunk), grid.n), dtype=torch.float64, device=engine.device())
         if tbl.n:
-            engine.voigt_sum(tbl, grid, Tk, pk, np.tile(w[:, None], (1, len(chunk))), out_f64=dev, dil_air=dil.get("air", 0.0),
-                             dil_self=dil.get("self", 0.0), omega_wing=WavenumberWing, omega_wing_hw=WavenumberWingHW,
-                             intensity_threshold=IntensityThreshold, scale=scale, profile=3 if tbl.has_sd else 0)
+            dev = torch.empty((len(chunk), grid.n), dtype=torch.float64, device=engine.device())
+            try:
+                engine.voigt_sum(tbl, grid, Tk, pk, np.tile(w[:, None], (1, len(chunk))), out_f64=dev, dil_air=dil.get("air", 0.0),
+                                 dil_self=dil.get("self", 0.0), omega_wing=WavenumberWing, omega_wing_hw=WavenumberWingHW,
+                                 intensity_threshold=IntensityThreshold, scale=scale, profile=3 if tbl.has_sd else 0)
+            except _lib.RtxError as e:
+                if "work list" in str(e) and per > 1:  # too many partial tiles for one launch: fewer states at a time
+                    per = max(1, per // 4)
+                    continue
+                raise
             out[s0:s0 + len(chunk)] = dev.cpu().numpy()
         else:
             out[s0:s0 + len(chunk)] = 0.0
+        s0 += len(chunk)
     return out.reshape(T.size, P.size, X.size)
 
 

@@ -127,7 +127,7 @@ struct rtx_lines {
 // tiles, and a last kernel adds a tile's parts to its optical depths in part order. The cut is a function of the
 // (canonical) candidate range alone, so results stay bit-reproducible and independent of how the axis is sharded.
 #ifndef RTX_SPLIT_PART
-#define RTX_SPLIT_PART 512
+#define RTX_SPLIT_PART 256
 #endif
 struct __attribute__((aligned(16))) SplitItem {
   int tile, k;    // tile of the shard, layer

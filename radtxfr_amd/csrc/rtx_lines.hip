@@ -457,7 +457,8 @@ static int rtx_split_bound(rtx_prep* P, const rtx_lines* L, const rtx_grid* g, i
   }
   extra *= n_layers;
   if (extra > P->items_cap) {  // grow-only; rare (a new table / grid / much wider wings): allocates, hence synchronises
-    if (extra > 4000000LL) RTX_FAIL("hot-tile work list of %lld items: the line table is too dense for this grid", extra);
+    if (extra > 1000000LL)  // 4 GB of partial tiles: callers with many states per launch split the launch (afit_xs.py)
+      RTX_FAIL("hot-tile work list of %lld items (over 1000000): fewer layers / states per call, or a shorter grid shard", extra);
     if (P->items) { RTX_HIP(hipFree(P->items)); P->items = nullptr; }
     if (P->part_ws) { RTX_HIP(hipFree(P->part_ws)); P->part_ws = nullptr; }
     P->items_cap = 0;

@@ -21,10 +21,13 @@ __device__ __forceinline__ cd cinv(cd a) {
   return {a.r * d, -a.i * d};
 }
 __device__ __forceinline__ cd cdiv(cd a, cd b) { return cmul(a, cinv(b)); }
-__device__ __forceinline__ double cabs(cd a) { return hypot(a.r, a.i); }
+// |a| without hypot's scaling (the arguments here are O(1e-6 .. 1e6): no overflow or underflow to guard against; the
+// library hypot costs more than the rest of the far-wing evaluation, and the 1-ulp difference is far below the 1e-9 the
+// parity tests hold this path to)
+__device__ __forceinline__ double cabs(cd a) { return sqrt(a.r * a.r + a.i * a.i); }
 // principal square root (numpy.sqrt on complex128)
 __device__ __forceinline__ cd csqrt_(cd z) {
-  const double m = hypot(z.r, z.i);
+  const double m = cabs(z);
   if (m == 0.0) return {0.0, z.i};
   if (z.r >= 0.0) {
     const double t = sqrt(0.5 * (m + z.r));
@@ -107,6 +110,22 @@ __device__ double sdvoigt_profile(const LineRecSD& q, double sg) {
     Z1.r -= csqrtY;
     const cd Z2 = {Z1.r + 2.0 * csqrtY, Z1.i};
     const double x1 = -Z1.i, y1 = Z1.r, x2 = -Z2.i, y2 = Z2.r;
+    if (fabs(x1) + y1 >= 15.0 && fabs(x2) + y2 >= 15.0) {
+      // Far wing -- with the reference caller's WavenumberWingHW = 350 (misc/RT_gen_AbsXS_files.py:90) all but the innermost
+      // ~0.02 cm^-1 of every window: both |Z| >= 15/sqrt(2) > 8, so the cpf3 switch (:9948-9958) is off and hum1_wei takes
+      // its one-term asymptote w = f(t)/sqrt(pi), f(t) = t/(1/2 + t^2), t = y - ix, for BOTH arguments (:9834-9840). Their
+      // difference is formed in closed form, f(t1) - f(t2) = (t1 - t2)(1/2 - t1 t2) / ((1/2 + t1^2)(1/2 + t2^2)), with
+      // t1 - t2 = -2 csqrtY exactly: the same quantity as the reference's W1 - W2 (to the ~1e-14 its cancellation leaves),
+      // at a tenth of the cost of two complex evaluations.
+      const cd t1 = {y1, -x1}, t2 = {y2, -x2};
+      const cd p12 = cmul(t1, t2);
+      cd d1 = cmul(t1, t1), d2 = cmul(t2, t2);
+      d1.r += 0.5;
+      d2.r += 0.5;
+      const cd nume = cscale(cd{0.5 - p12.r, -p12.i}, -2.0 * csqrtY);
+      A = cscale(cdiv(nume, cmul(d1, d2)), cte);  // sqrt(pi) cte (W1 - W2), W = f/sqrt(pi)
+      return A.r * (1.0 / M_PI);
+    }
     const double S1 = sqrt(x1 * x1 + y1 * y1), S2 = sqrt(x2 * x2 + y2 * y2);
     const bool use3 = fabs(S1 - S2) <= 1.0 && fmax(S1, S2) > 8.0 && fmin(S1, S2) <= 8.0;
     const cd W1 = use3 ? cpf3_c(x1, y1) : hum1_wei_c(x1, y1);
@@ -159,8 +178,10 @@ __global__ __launch_bounds__(256) void sdvoigt_kernel(SdArgs a) {
   const LineRecSD* __restrict__ rsd = a.recsd + (size_t)k * (size_t)a.n_lines;
   double acc = 0.0;
   const int ii = (int)i;
+  const int b_lo = (int)i0, b_hi = (int)(i0 + 256 < a.g.n ? i0 + 256 : a.g.n);
   for (int l = s_rng[0]; l < s_rng[1]; ++l) {
     const int lo = rec[l].lo, hi = rec[l].hi;  // empty windows have lo = hi = 0
+    if (hi <= b_lo || lo >= b_hi) continue;    // the whole block lies outside this line's window (uniform branch)
     if (ii >= lo && ii < hi) {
       const LineRecSD q = rsd[l];
       acc += q.WS * sdvoigt_profile(q, sg);

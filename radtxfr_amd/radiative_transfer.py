@@ -25,6 +25,7 @@ Conscious divergences from the reference:
 """
 import os
 import threading
+import time
 
 import numpy as np
 import torch
@@ -195,6 +196,7 @@ def _cached_axis(Xmin, Xmax, DVOUT):
 
 
 _STAGING = {}
+_TRACE = float(os.environ.get("RADTXFR_TRACE", "0") or 0)  # developer aid: print the phases of slow compute_TUD calls
 
 
 def _rows_to_host_f64(rows, stream=None):
@@ -238,6 +240,7 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     spectra are fresh float64 arrays -- views of page-locked memory while less than _hostio.PINNED_RESULT_CAP is lent
     out to live results, ordinary pageable arrays beyond that.
     """
+    trace = [time.perf_counter()] if _TRACE else None
     o = dict(opts)
     o.update(kwargs)
     Z = np.asarray(o["Zs"], dtype=np.float64)
@@ -252,7 +255,11 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     mu_s = f(1.0 / np.cos(o["theta_r"]))
     X_ = _cached_axis(Xmin, Xmax, o["DVOUT"])
     grid = engine.Grid(Xmin, Xmax, X_.size)
+    if trace:
+        trace.append(time.perf_counter())
     tbl = _resolve_table(o.get("line_table"))
+    if trace:
+        trace.append(time.perf_counter())
     if o.get("copy_axis"):
         X_ = _hostio.copy_threaded(X_)
     if mu_s.size <= engine.TUD_MAX_MU and not o["save"]:
@@ -267,8 +274,17 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
         res = engine.tud(OD, grid, T, Z, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64), N_angle=nA,
                          returnOD=bool(o["returnOD"]), per_angle=bool(o["save"]))
         tau, Lu, Ld, (nZ, nMu) = res[:4]
+    if trace:
+        trace.append(time.perf_counter())
     (tau_h, Lu_h, Ld_h), done = _rows_to_host_f64([tau, Lu, Ld[None, :]])
+    if trace:
+        trace.append(time.perf_counter())
     done.synchronize()
+    if trace:
+        trace.append(time.perf_counter())
+        if trace[-1] - trace[0] > _TRACE * 1e-3:  # RADTXFR_TRACE=<ms>: phases of every call slower than that
+            print("compute_TUD %.1f ms: options+axis %.2f  table %.2f  enqueue kernels %.2f  enqueue copies %.2f  wait %.2f"
+                  % tuple(1e3 * v for v in [trace[-1] - trace[0]] + [b - a for a, b in zip(trace, trace[1:])]), flush=True)
     tau_, Lu_ = _tud_shapes(tau_h, Lu_h, nZ, nMu)
     Ld_ = Ld_h[0]
     if o["save"]:

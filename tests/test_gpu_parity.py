@@ -773,6 +773,37 @@ def test_g11_sdvoigt_golden(hapi, golden):
     assert rel_err(xt, xo) <= 1e-7 and rel_err(xt, xv) <= 1e-6
 
 
+def test_cross_sections_at_the_reference_callers_settings(hapi):
+    """The reference's one in-tree hapi caller (misc/RT_gen_AbsXS_files.py:15-18, 86-92) runs absorptionCoefficient_SDVoigt
+    with WavenumberStep = 0.0025 and WavenumberWingHW = 350: windows of +-350 gamma0 = +-25 ... 38 cm^-1 at one atmosphere,
+    seven times wider than the default 50. A 200 cm^-1 slice of that configuration (80 001 points, 2500 lines with wings
+    reaching in from 40 cm^-1 outside) against the oracle, for a table without speed-dependence columns (Gamma2 = 0: pcqsdhc
+    PART1, the fp32 Voigt line-sum with its row-level nodes on windows this wide) and with SD_air (PART4 in fp64, almost
+    all of it the closed-form far-wing difference), at the surface state and at 0.05 atm."""
+    from radtxfr_amd import afit_xs
+    tbl = dict(synthetic.synth_line_table(77, 2500, 760.0, 1040.0))
+    X = np.linspace(800.0, 1000.0, 80001)
+    hapi.storage2cache_from_columns("xs350", tbl)
+    for T, p in ((296.0, 1.0), (260.0, 0.05)):
+        _, xv = hapi.absorptionCoefficient_SDVoigt(SourceTables="xs350", Environment={"T": T, "p": p}, WavenumberGrid=None, OmegaGrid=X,
+                                                   WavenumberWingHW=350.0)
+        _, xr = ref.absorptionCoefficient_Voigt(tbl, T=T, p=p, OmegaGrid=X, OmegaWingHW=350.0)
+        assert rel_err(xv, xr) <= TOL_L, (T, p, rel_err(xv, xr))
+    sd = dict(tbl)
+    sd["SD_air"] = np.round(np.random.default_rng(78).uniform(0.05, 0.2, 2500), 3)
+    hapi.storage2cache_from_columns("xs350sd", sd)
+    for T, p in ((296.0, 1.0), (260.0, 0.05)):
+        _, xs = hapi.absorptionCoefficient_SDVoigt(SourceTables="xs350sd", Environment={"T": T, "p": p}, OmegaGrid=X, WavenumberWingHW=350.0)
+        _, xr = ref.absorptionCoefficient_SDVoigt(sd, T=T, p=p, OmegaGrid=X, OmegaWingHW=350.0)
+        assert rel_err(xs, xr) <= 1e-9, (T, p, rel_err(xs, xr))
+    # the batched T x p generator on the same table equals the per-state calls
+    xs_grid = afit_xs.cross_section_grid("xs350sd", [296.0], [1.0], X, WavenumberWingHW=350.0)
+    _, one = hapi.absorptionCoefficient_SDVoigt(SourceTables="xs350sd", Environment={"T": 296.0, "p": 1.0}, OmegaGrid=X, WavenumberWingHW=350.0)
+    assert rel_err(xs_grid[0, 0], one) <= 1e-12
+    for n in ("xs350", "xs350sd"):
+        hapi.LOCAL_TABLE_CACHE.pop(n)
+
+
 def test_afit_xs_grid_batched_states(hapi, tmp_path):
     """afit_xs.cross_section_grid / generate_xs_files (the T x p loop of misc/RT_gen_AbsXS_files.py:86-92 as one
     batched launch): every state equals the per-state hapi shim call and agrees with the oracle; files round-trip."""
