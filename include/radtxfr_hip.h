@@ -111,7 +111,7 @@ int rtx_line_prep(rtx_prep* prep, const rtx_lines* lines, const rtx_grid* grid, 
 /* Hot tiles (line lists cluster: a band head puts thousands of candidate lines on one line-sum tile, and one workgroup per
  * tile would serialise the launch). The prologue bounds, on the host, the candidates any tile of `grid` can have -- no
  * window is wider than max(OmegaWing, OmegaWingHW * gamma, misc/hapi.py:11131) with the table's column extremes -- and
- * rtx_voigt_sum cuts tiles with more than 256 candidates into parts evaluated by extra workgroups and summed in a fixed
+ * rtx_voigt_sum cuts tiles with more than 768 candidates into parts of 256 evaluated by extra workgroups and summed in a fixed
  * order (results stay bit-reproducible and independent of wavenumber sharding). This returns the number of extra parts
  * the last prologue allowed for: 0 = no tile of that table / grid can be hot and the extra kernels are never launched.
  * A bound that grows (new table or grid, much wider wings) re-allocates the part workspace inside rtx_line_prep*: the one

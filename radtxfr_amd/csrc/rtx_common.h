@@ -121,13 +121,16 @@ struct rtx_lines {
 // ---- hot tiles ---------------------------------------------------------------------------------------
 // Real line lists cluster (band heads: thousands of lines inside a cm^-1), and one line-sum workgroup per (tile, layer)
 // then serialises the launch on its few hot tiles (the clustered synthetic table: slowest workgroup = 2x the ideal
-// duration of the whole launch, tools/tile_spread.py). A tile with more than RTX_SPLIT_PART candidates is therefore cut
+// duration of the whole launch, tools/tile_spread.py). A tile with more than RTX_SPLIT_MIN candidates is therefore cut
 // into parts of RTX_SPLIT_PART consecutive candidates: part 0 stays with the tile's own workgroup, every further part is
 // an item of a work list (written by tile_ranges_kernel) that extra workgroups evaluate into a workspace of partial
 // tiles, and a last kernel adds a tile's parts to its optical depths in part order. The cut is a function of the
 // (canonical) candidate range alone, so results stay bit-reproducible and independent of how the axis is sharded.
 #ifndef RTX_SPLIT_PART
-#define RTX_SPLIT_PART 256
+#define RTX_SPLIT_PART 256  // candidates per part (clustered C3 table, prologue + line-sum: 512 -> 2.83 ms, 256 -> 2.57, 128 -> 2.83; unsplit 5.47)
+#endif
+#ifndef RTX_SPLIT_MIN
+#define RTX_SPLIT_MIN 768   // tiles with more candidates than this are cut: three times a part, so that the ~100-300 candidates of an ordinary tile never are
 #endif
 struct __attribute__((aligned(16))) SplitItem {
   int tile, k;    // tile of the shard, layer

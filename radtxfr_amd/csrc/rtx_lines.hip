@@ -453,7 +453,7 @@ static int rtx_split_bound(rtx_prep* P, const rtx_lines* L, const rtx_grid* g, i
     if (b < a) b = a;
     while (b < L->n && L->nu_host[b] <= xb) ++b;
     const long long cnt = b - a;
-    if (cnt > RTX_SPLIT_PART) extra += (cnt - 1) / RTX_SPLIT_PART;
+    if (cnt > RTX_SPLIT_MIN) extra += (cnt - 1) / RTX_SPLIT_PART;
   }
   extra *= n_layers;
   if (extra > P->items_cap) {  // grow-only; rare (a new table / grid / much wider wings): allocates, hence synchronises

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
     // slots, part 1 first). The list is sized from a host-side bound (rtx_split_bound) and cannot overflow; should it ever,
     // the tile is simply left whole.
     const long long cnt = last - first;
-    if (a.items && cnt > RTX_SPLIT_PART) {
+    if (a.items && cnt > RTX_SPLIT_MIN) {
       const int extra = (int)((cnt - 1) / RTX_SPLIT_PART);
       const long long at = (long long)atomicAdd(a.n_items, extra);
       if (at + extra <= a.items_cap) {

@@ -185,7 +185,7 @@ def test_clustered_table_full_grid_properties():
     OD = engine.optical_depths(lines, grid, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
     torch.cuda.synchronize()
     assert bool(torch.isfinite(OD).all()) and float(OD.min()) >= 0.0
-    # the band heads put > 512 candidates on some tiles: those are cut into parts (rtx_prep_split_bound > 0); the uniform
+    # the band heads put > 768 candidates on some tiles: those are cut into parts (rtx_prep_split_bound > 0); the uniform
     # benchmark table has no such tile and never launches the extra kernels
     lib = _lib.load()
     assert lib.rtx_prep_split_bound(lines.plan(32, grid.n)._h) > 100

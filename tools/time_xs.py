@@ -28,5 +28,21 @@ for label, sd in (("no SD columns (Voigt line-sum, fp32)", False), ("SD_air 0.05
         xs = afit_xs.cross_section_grid("xs", T, [1.0], X, WavenumberWingHW=350.0)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print(f"{label}: {X.size} points x {args.lines} lines, {args.states} states at 1 atm, HW 350: {dt * 1e3 / args.states:.1f} ms per (T, p) state "
-          f"(incl. device-to-host copy of {X.size * 8 / 1e6:.0f} MB per state); checksum {xs.sum():.6e}", flush=True)
+    # the device part alone (prologue + line-sum of all states in one launch), HIP events
+    from radtxfr_amd import engine
+    lines = hapi._device_table(["xs"])
+    grid = engine.Grid.from_axis(X)
+    w = np.array([[hapi.abundance(*mi) / hapi.abundance(*mi)] * args.states for mi in lines.species])
+    dev = torch.empty((args.states, grid.n), dtype=torch.float64, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ts = []
+    for rep in range(3):
+        torch.cuda.synchronize()
+        ev[0].record()
+        engine.voigt_sum(lines, grid, T, np.ones(args.states), w, out_f64=dev, omega_wing_hw=350.0, scale=2.0 ** 70, profile=3 if sd else 0)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ts.append(ev[0].elapsed_time(ev[1]) / args.states)
+    print(f"{label}: {X.size} points x {args.lines} lines, {args.states} states at 1 atm, HW 350: device {np.median(ts):.2f} ms per (T, p) state "
+          f"(HIP events, prologue + line-sum); {dt * 1e3 / args.states:.1f} ms per state through afit_xs.cross_section_grid incl. the "
+          f"device-to-host copy of {X.size * 8 / 1e6:.0f} MB per state; checksum {xs.sum():.6e}", flush=True)
