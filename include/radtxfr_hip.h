@@ -290,6 +290,26 @@ int rtx_fir_reflect(const void* in, int in_is_f64, int64_t ld_in, int n_rows, in
 int rtx_cubic_resample(const double* Ysm, int64_t ld, int n_rows, int64_t n, double x0, double h,
                        const double* x_out, int64_t n_out, double* out, int64_t ld_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Single-process collectives over the GPUs of one node. The reference has no multi-GPU code; its scripts are plain
+ * Python programs that fan work out with multiprocessing (Generate_LWIR_TUD.py:117-150). These three calls let ONE host
+ * process shard a spectrum over several devices and reassemble it -- the one exchange of the path: the all-gather of the
+ * packed [tau, L-up, L-down] blocks (radtxfr_amd/dist.py: compute_TUD_local) -- without a launcher.
+ *   rtx_comm_init_all  devs_h[ndev] device indices. backend -1: RCCL (ncclCommInitAll, resolved at run time from the
+ *                      librccl the process already holds, else librccl.so) when it loads and the devices are distinct,
+ *                      otherwise peer copies; 0: peer copies (hipMemcpyPeerAsync fan-out; a device may repeat); 1: RCCL or
+ *                      fail. Environment RADTXFR_COMM=peer|rccl overrides. Allocates and synchronises.
+ *   rtx_comm_backend   0 peer copies, 1 RCCL
+ *   rtx_allgather      rank i contributes sendbufs_h[i][0..count) float32 on device devs[i]; afterwards every
+ *                      recvbufs_h[j][i*count + t] = sendbufs_h[i][t]. streams_h[i] is rank i's stream (send block complete
+ *                      in its order before, gathered block complete in its order after). Asynchronous to the host. */
+typedef struct rtx_comm rtx_comm;
+int rtx_comm_init_all(int ndev, const int* devs_h, int backend, rtx_comm** out);
+int rtx_comm_backend(const rtx_comm* comm);
+int rtx_allgather(rtx_comm* comm, const void* const* sendbufs_h, void* const* recvbufs_h, int64_t count,
+                  void* const* streams_h);
+int rtx_comm_destroy(rtx_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

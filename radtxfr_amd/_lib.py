@@ -58,6 +58,10 @@ PROTOTYPES = {
     "rtx_cubic_resample": (_i32, [_vp, _i64, _i32, _i64, _dbl, _dbl, _vp, _i64, _vp, _i64, _vp]),
     "rtx_brightness_temperature": (_i32, [_vp, _i64, _vp, _i64, _i32, _dbl, _vp, _vp]),
     "rtx_bt2l": (_i32, [_vp, _i64, _vp, _i64, _i32, _dbl, _vp, _vp]),
+    "rtx_comm_init_all": (_i32, [_i32, _vp, _i32, C.POINTER(_vp)]),
+    "rtx_comm_backend": (_i32, [_vp]),
+    "rtx_allgather": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "rtx_comm_destroy": (_i32, [_vp]),
 }
 
 _lib = None

@@ -9,6 +9,9 @@
 
 #include "rtx_voigt_math.h"
 
+#ifndef RTX_SD_FARWING
+#define RTX_SD_FARWING 1  // 0: every point through the two complex probability functions, as in round 2 (timing comparisons)
+#endif
 struct cd {
   double r, i;
 };
@@ -110,7 +113,7 @@ __device__ double sdvoigt_profile(const LineRecSD& q, double sg) {
     Z1.r -= csqrtY;
     const cd Z2 = {Z1.r + 2.0 * csqrtY, Z1.i};
     const double x1 = -Z1.i, y1 = Z1.r, x2 = -Z2.i, y2 = Z2.r;
-    if (fabs(x1) + y1 >= 15.0 && fabs(x2) + y2 >= 15.0) {
+    if (RTX_SD_FARWING && fabs(x1) + y1 >= 15.0 && fabs(x2) + y2 >= 15.0) {
       // Far wing -- with the reference caller's WavenumberWingHW = 350 (misc/RT_gen_AbsXS_files.py:90) all but the innermost
       // ~0.02 cm^-1 of every window: both |Z| >= 15/sqrt(2) > 8, so the cpf3 switch (:9948-9958) is off and hum1_wei takes
       // its one-term asymptote w = f(t)/sqrt(pi), f(t) = t/(1/2 + t^2), t = y - ix, for BOTH arguments (:9834-9840). Their

@@ -159,6 +159,80 @@ def compute_TUD_sharded(Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, PLs, MFs_VAL,
     return np.linspace(Xmin, Xmax, n_total), full[0], full[1], full[2]
 
 
+class LocalShardedTud:
+    """compute_TUD with the spectral axis sharded over several GPUs by ONE host process (no torchrun, no process group):
+    the same tile-aligned, cost-weighted shards as compute_TUD_sharded -- hence the same bits as a single-device run -- one
+    line-table subset, runner and stream per device, and one comm.LocalComm.all_gather (RCCL over xGMI, or peer copies) of
+    the packed [tau, L-up, L-down] blocks. Set up once per (grid, table, altitude grid); run() per atmosphere is
+    asynchronous apart from the per-atmosphere host factors.
+
+        sh = LocalShardedTud(devices, Xmin, Xmax, DVOUT, table, Zs, Ts, Ps)   # Ts, Ps: a typical atmosphere, for the plan
+        X, tau, Lu, Ld = sh.run(Ts, Ps, PLs, MFs_VAL, MFs_ID)                  # float32 views on devices[0]
+    """
+
+    def __init__(self, devices, Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, Altitudes=(500,), theta_r=0.0, N_angle=30, balance=True,
+                 backend=-1):
+        from . import comm, engine
+        self.devices = [int(d) for d in devices]
+        world = len(self.devices)
+        self.n_total = int(np.ceil((Xmax - Xmin) / DVOUT))
+        self.Xmin, self.Xmax = float(Xmin), float(Xmax)
+        grid_full = engine.Grid(Xmin, Xmax, self.n_total)
+        with torch.cuda.device(self.devices[0]):
+            self.offs, reach = tud_shard_plan(line_table, Xmin, Xmax, self.n_total, Ts, Ps, world, balance)
+        self.per = int(np.diff(self.offs).max())
+        self.comm = comm.LocalComm(self.devices, backend) if world > 1 else None
+        self.ranks = []
+        step = grid_full.step
+        for r, d in enumerate(self.devices):
+            off, n_loc = int(self.offs[r]), int(self.offs[r + 1] - self.offs[r])
+            with torch.cuda.device(d):
+                st = torch.cuda.Stream()
+                packed = torch.zeros((3, self.per), dtype=torch.float32, device="cuda")
+                gathered = torch.empty((world * 3 * self.per,), dtype=torch.float32, device="cuda") if world > 1 else None
+                run = lines = None
+                if n_loc > 0:
+                    grid = grid_full.shard(off, n_loc)
+                    sub = subset_lines(line_table, Xmin + off * step, Xmin + (off + n_loc - 1) * step, reach)
+                    lines = engine.LineTable(sub)
+                    with torch.cuda.stream(st):
+                        run = engine.TudRunner(lines, grid, Zs, n_layers=np.asarray(Ts).size, Altitudes=Altitudes, theta_r=theta_r,
+                                               N_angle=N_angle, out=(packed[0:1], packed[1:2], packed[2]),
+                                               plan=engine.VoigtPlan(lines, np.asarray(Ts).size, n_loc))
+            self.ranks.append(dict(dev=d, stream=st, packed=packed, gathered=gathered, run=run, lines=lines))
+
+    def run(self, Ts, Ps, PLs, MFs_VAL, MFs_ID):
+        world = len(self.devices)
+        for rk in self.ranks:
+            if rk["run"] is not None:
+                with torch.cuda.device(rk["dev"]), torch.cuda.stream(rk["stream"]):
+                    rk["run"].run(Ts, Ps, PLs, MFs_VAL, MFs_ID)
+        r0 = self.ranks[0]
+        if world == 1:
+            full = r0["packed"][:, :self.n_total]
+        else:
+            self.comm.all_gather([rk["packed"].view(-1) for rk in self.ranks], [rk["gathered"] for rk in self.ranks],
+                                 [rk["stream"] for rk in self.ranks])
+            with torch.cuda.device(r0["dev"]), torch.cuda.stream(r0["stream"]):
+                g3 = r0["gathered"].view(world, 3, self.per)
+                full = torch.cat([g3[r, :, :int(self.offs[r + 1] - self.offs[r])] for r in range(world)], dim=1)
+        torch.cuda.current_stream(r0["dev"]).wait_stream(r0["stream"])  # the caller's stream on devices[0] sees the result
+        return np.linspace(self.Xmin, self.Xmax, self.n_total), full[0], full[1], full[2]
+
+    def close(self):
+        for rk in self.ranks:
+            with torch.cuda.device(rk["dev"]):
+                torch.cuda.synchronize()
+                if rk["run"] is not None:
+                    rk["run"].plan.close()
+                if rk["lines"] is not None:
+                    rk["lines"].close()
+        self.ranks = []
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
 def all_gather_rows(local, n_rows_total, group=None):
     """local: [n_loc][M] tensor holding this rank's shard_bounds() slice of the first axis.
     Returns [n_rows_total][M] on every rank (one all_gather_into_tensor of a padded block)."""

@@ -125,3 +125,40 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     if rec:
         with open(rec, "w") as f:
             f.write(line + "\n")
+
+
+def test_single_process_sharded_tud_and_local_comm():
+    """ONE host process, several ranks (dist.LocalShardedTud + comm.LocalComm: rtx_comm_init_all / rtx_allgather): the
+    reference's scripts have no launcher, so the wavenumber-sharded path must be reachable without torchrun. The box has one
+    GPU: ranks share device 0 through the peer-copy backend (2 and 3 ranks, ragged and empty shards) and must reproduce the
+    single-device spectra BIT FOR BIT for several atmospheres; RCCL itself is brought up on the one device (ncclCommInitAll
+    through the run-time loader) and moves a block."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mp_worker
+    from radtxfr_amd import comm, dist as rdist
+    lo, hi, dv, sub, a = mp_worker.tud_case()
+    X1, tau1, Lu1, Ld1 = rdist.compute_TUD_sharded(lo, hi, dv, sub, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    for devs in ([0, 0], [0, 0, 0], [0, 0, 0, 0, 0]):
+        sh = rdist.LocalShardedTud(devs, lo, hi, dv, sub, a["Zs"], a["Ts"], a["Ps"])
+        assert sh.comm.backend == "peer" and sh.offs[-1] == 3001 and all(v % 1024 == 0 for v in sh.offs[1:-1] if v < 3001)
+        for scale in (1.0, 0.5):
+            X, tau, Lu, Ld = sh.run(a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"] * scale, a["MFs_ID"])
+            torch.cuda.synchronize()
+            if scale == 1.0:
+                assert np.array_equal(X, X1)
+                for got, one in ((tau, tau1), (Lu, Lu1), (Ld, Ld1)):
+                    assert torch.equal(got, one), (devs, float((got - one).abs().max()))
+            else:
+                assert float(tau.mean()) > float(tau1.mean())
+        sh.close()
+    c = comm.LocalComm([0])
+    assert c.backend == "rccl", "librccl was not found by the run-time loader"
+    send = torch.arange(1000, dtype=torch.float32, device="cuda")
+    recv = torch.zeros(1000, dtype=torch.float32, device="cuda")
+    c.all_gather([send], [recv])
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    c.close()
+    with pytest.raises(Exception):
+        comm.LocalComm([0, 0], backend=1)  # RCCL refuses a repeated device

@@ -8,10 +8,10 @@ mkdir -p "$ROOT/build/$NAME"
 cd "$ROOT/radtxfr_amd/csrc"
 rm -f "$ROOT/build/$NAME.so" "$ROOT"/build/$NAME/*.o
 pids=""
-for f in rtx_lines rtx_voigt rtx_voigt_scatter rtx_sdvoigt rtx_tud rtx_radiance rtx_resample; do
+for f in rtx_lines rtx_voigt rtx_voigt_scatter rtx_sdvoigt rtx_tud rtx_radiance rtx_resample rtx_comm; do
   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $EXTRA -Wno-unused-function -c $f.hip -o "$ROOT/build/$NAME/$f.o" &
   pids="$pids $!"
 done
 for p in $pids; do wait $p || { echo "compile failed for variant $NAME" >&2; exit 1; }; done
-hipcc -shared --offload-arch=gfx950 -o "$ROOT/build/$NAME.so" "$ROOT"/build/$NAME/*.o
+hipcc -shared --offload-arch=gfx950 -o "$ROOT/build/$NAME.so" "$ROOT"/build/$NAME/*.o -ldl
 echo "$ROOT/build/$NAME.so"
