@@ -104,6 +104,7 @@ struct __attribute__((aligned(16))) LineRec64 {
 // and the line's weight * S(T).
 struct __attribute__((aligned(16))) LineRecSD {
   double nu, cte, Gam0, Shift0, Gam2, WS;
+  double inv_Gam2, csqrtY;  // 1 / Gam2 and 1 / (2 cte Gam2): per-line reciprocals the line-sum would otherwise redo per point
 };
 
 struct rtx_lines {

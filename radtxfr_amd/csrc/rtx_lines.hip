@@ -390,6 +390,8 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       if (a.dil_self != 0.0 && a.sd_self) Gam2 += a.dil_self * (a.sd_self[l] * p) * a.gamma_self[l];
       LineRecSD q;
       q.nu = nu; q.cte = cte; q.Gam0 = Gamma0; q.Shift0 = Shift0; q.Gam2 = Gam2; q.WS = dropped ? 0.0 : w * S;
+      q.inv_Gam2 = Gam2 != 0.0 ? 1.0 / Gam2 : 0.0;
+      q.csqrtY = Gam2 != 0.0 ? 1.0 / (2.0 * cte * Gam2) : 0.0;
       a.recsd[o] = q;
     }
     if (!dropped && ghi > glo) {

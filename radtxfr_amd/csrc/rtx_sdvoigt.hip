@@ -89,17 +89,19 @@ __device__ double sdvoigt_profile(const LineRecSD& q, double sg) {
     return rpi * cte * hum1_wei_c(-Z1.i, Z1.r).r * (1.0 / M_PI);
   }
   const double c2t = q.Gam2;
-  const cd X = cscale(num, 1.0 / c2t);
-  const double csqrtY = 1.0 / (2.0 * cte * c2t);  // (Gam2 - i 0) / (2 cte Gam2^2)
+  const cd X = cscale(num, q.inv_Gam2);  // 1 / c2t, from the prologue (the same division, once per line instead of per point)
+  const double csqrtY = q.csqrtY;        // 1 / (2 cte c2t) = (Gam2 - i 0) / (2 cte Gam2^2)
   const double Y = csqrtY * csqrtY;               // 1 / (2 cte c2t)^2
-  const double aX = cabs(X);
+  // |X| against the two thresholds by its SQUARE (fp64 sqrt is a 20-instruction sequence; the branches are continuous
+  // across their thresholds, so the last-bit difference of the comparison cannot be seen)
+  const double aX2 = X.r * X.r + X.i * X.i;
   cd A;
-  if (aX <= 3.0e-8 * Y) {  // PART2 (:9974-9989)
+  if (aX2 <= (3.0e-8 * Y) * (3.0e-8 * Y)) {  // PART2 (:9974-9989)
     const cd Z1 = cscale(num, cte);
     cd Z2 = csqrt_(cd{X.r + Y, X.i});
     Z2.r += csqrtY;
     A = cscale(csub(hum1_wei_c(-Z1.i, Z1.r), hum1_wei_c(-Z2.i, Z2.r)), rpi * cte);
-  } else if (Y <= 1.0e-15 * aX) {  // PART3 (:9992-10017)
+  } else if (Y * Y <= 1.0e-30 * aX2) {  // PART3 (:9992-10017): Y <= 1e-15 |X|
     const cd sq = csqrt_(X);
     if (cabs(sq) <= 4.0e3) {
       const cd t = cmul(sq, hum1_wei_c(-sq.i, sq.r));
