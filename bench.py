@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipelines", type=int, default=2,
+                    help="independent pipelines (stream + records + OD buffer each) the atmospheres of the timed loop alternate over")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, gather staged through the host); never a measurement")
     args = ap.parse_args()
@@ -172,11 +174,11 @@ def main():
     # RCCL all-gather of step k overlaps the kernels of step k+1 (separate stream, async_op). The timed region ends
     # with every gather complete (drain + barrier + synchronize): throughput of a pipelined stream of atmospheres, the
     # reference's own use (199 atmospheres per run, Generate_LWIR_TUD.py:117-150), not the latency of one.
-    gathered = [torch.empty((world * 3 * per,), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-    packed = [torch.zeros((3, per), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
+    NP = max(1, args.pipelines)
+    gathered = [torch.empty((world * 3 * per,), dtype=torch.float32, device=dev) for _ in range(NP)] if world > 1 else None
+    packed = [torch.zeros((3, per), dtype=torch.float32, device=dev) for _ in range(NP)] if world > 1 else None
+    pending = [None] * NP
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    counter = [0]
     last = {}
 
     def host_factors(mf):
@@ -185,33 +187,41 @@ def main():
         qratio, mass = engine.species_factors(lines.species, T, weight=w)
         return w, p_atm, qratio, mass
 
-    # one call into the library per atmosphere (rtx_compute_tud): host factors + prologue + line-sum + TUD
-    runner = engine.TudRunner(lines, grid, Z, n_layers=N_LAYERS, OD=OD,
-                              out=(packed[0][0:1], packed[0][1:2], packed[0][2]) if world > 1 else None) if n_loc > 0 else None
+    # one call into the library per atmosphere (rtx_compute_tud): host factors + prologue + line-sum + TUD. The atmospheres
+    # of the loop alternate over NP independent pipelines (engine.TudPipelines: stream + records + OD buffer each), so that
+    # the prologue and the TUD pass of one atmosphere overlap the line-sum of the next: a stream of atmospheres is the
+    # reference's own workload (199 per run, Generate_LWIR_TUD.py:117-150). N > 1: pipeline p writes straight into packed
+    # block p, whose all-gather (async, RCCL's own stream) overlaps the kernels of the following atmospheres.
+    pipes = engine.TudPipelines(lines, grid, Z, n_layers=N_LAYERS, n_pipes=NP,
+                                outs=[(pk[0:1], pk[1:2], pk[2]) for pk in packed] if world > 1 else None) if n_loc > 0 else None
+    runner = pipes.runs[0] if pipes is not None else None
+    counter = [0]
 
     def step():
         if world == 1:
-            last["out"] = runner.run(T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
+            last["p"], last["out"] = pipes.run(T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
             return
-        b = counter[0] & 1
+        b = counter[0] % NP
         counter[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()  # this block's previous all-gather must be done before it is overwritten
-            pending[b] = None
         pk = packed[b]
-        if runner is not None:
-            runner.set_outputs(pk[0:1], pk[1:2], pk[2])
-            runner.run(T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
-        if args.backend == "nccl":
-            pending[b] = dist.all_gather_into_tensor(gathered[b], pk.view(-1), async_op=True)
-        else:
-            g_cpu = torch.empty(gathered[b].shape, dtype=gathered[b].dtype)
-            dist.all_gather_into_tensor(g_cpu, pk.view(-1).cpu())
-            gathered[b].copy_(g_cpu)
+        st_b = pipes.streams[b] if pipes is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(st_b):
+            if pending[b] is not None:
+                pending[b].wait()  # (stream b waits) this block's previous all-gather must be done before it is overwritten
+                pending[b] = None
+            if pipes is not None:
+                pipes.k = b
+                pipes.run(T, atm["Ps"], atm["PLs"], atm["MFs_VAL"], atm["MFs_ID"])
+            if args.backend == "nccl":
+                pending[b] = dist.all_gather_into_tensor(gathered[b], pk.view(-1), async_op=True)
+            else:
+                g_cpu = torch.empty(gathered[b].shape, dtype=gathered[b].dtype)
+                dist.all_gather_into_tensor(g_cpu, pk.view(-1).cpu())
+                gathered[b].copy_(g_cpu)
         last["b"] = b
 
     def drain():
-        for b in range(2):
+        for b in range(NP):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
@@ -396,7 +406,8 @@ def main():
             "config": {"workload": "C3: 32-layer TUD (tau,Lu,Ld) StandardAtmosphere rows 1-32, 500-6000 cm^-1 @ 0.001 cm^-1",
                        "n_wavenumbers": N_WAVENUMBERS, "n_layers": N_LAYERS, "n_lines": N_LINES, "n_angles": 30,
                        "line_table": "synthetic HITRAN-format H2O+CO2, seed 20261005",
-                       "parallelism": f"wavenumber-sharded x{world}" + (" + 1 RCCL all-gather" if world > 1 else "")},
+                       "parallelism": f"wavenumber-sharded x{world}" + (" + 1 RCCL all-gather" if world > 1 else ""),
+                       "pipelines_per_gpu": NP},
             "roofline": {"kernel": "voigt_nodal_kernel",
                          # the kernel moves 1.1x its algorithmic bytes and is nowhere near HBM speed: what binds it is
                          # vector-instruction issue (SURVEY 8d stage A). The contract's HBM figures stay in

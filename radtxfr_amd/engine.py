@@ -464,6 +464,39 @@ class TudRunner:
         return self.tau, self.Lu, self.Ld
 
 
+class TudPipelines:
+    """P independent TudRunners for a stream of atmospheres on one grid / table: each has its own HIP stream, per-(line,
+    layer) records (VoigtPlan), optical-depth buffer and outputs, and atmosphere k runs on pipeline k mod P. Within a
+    pipeline the four kernels of a step run back to back; across pipelines the fp64 prologue and the HBM-bound TUD pass of
+    one atmosphere share the chip with the VALU-bound line-sum of the next (C3 on MI355X, bench.py: 1.97 / 1.90 / 1.90 /
+    1.91 ms per atmosphere with 1 / 2 / 3 / 4 pipelines; profiles/r3_time_pipeline.txt). Results are the single-runner results bit for bit.
+    outs: optional list of P (tau, Lu, Ld) output triples (e.g. rows of packed blocks that are all-gathered)."""
+
+    def __init__(self, lines, grid, Z, n_layers=None, n_pipes=2, outs=None, **kw):
+        self.streams = [torch.cuda.Stream() for _ in range(int(n_pipes))]
+        self.runs = []
+        nL = int(np.atleast_1d(Z).size if n_layers is None else n_layers)
+        for p, s in enumerate(self.streams):
+            with torch.cuda.stream(s):
+                self.runs.append(TudRunner(lines, grid, Z, n_layers=nL, plan=VoigtPlan(lines, nL, grid.n),
+                                           out=None if outs is None else outs[p], **kw))
+        self.k = 0
+
+    def run(self, T, P_pa, PL_km, MF_VAL, MF_ID):
+        """Enqueue one atmosphere on the next pipeline; returns (pipeline index, (tau, Lu, Ld) of that pipeline)."""
+        p = self.k % len(self.runs)
+        self.k += 1
+        with torch.cuda.stream(self.streams[p]):
+            out = self.runs[p].run(T, P_pa, PL_km, MF_VAL, MF_ID)
+        return p, out
+
+    def close(self):
+        torch.cuda.synchronize()
+        for r in self.runs:
+            r.plan.close()
+        self.runs = []
+
+
 def planck(X, T, wavelength=False, grid=None):
     """out[nx][nT] float64 device tensor (rtx_planck). X: device fp64 tensor, or None with a Grid."""
     lib = _lib.load()

@@ -298,21 +298,24 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
 
 class _TudPipeline:
     """One device's share of compute_TUD_batch: the line table's copy on that device, two runners (two sets of device
-    outputs: the copy of one is in flight while the other is being computed) on a compute stream of its own, a side
-    stream for the device-to-host copies, a pinned staging ring."""
+    outputs: the copy of one is in flight while the other is being computed), each on a compute stream of its own, a
+    side stream for the device-to-host copies, a pinned staging ring."""
 
     def __init__(self, dev, tbl, grid, Z, nL, Z_s, theta_r, N_angle, returnOD):
         self.dev = int(dev)
         with torch.cuda.device(self.dev):
             self.lines = tbl.on_device(self.dev)
-            self.compute = torch.cuda.Stream()
             self.side = torch.cuda.Stream()
-            # a plan of its own: another pipeline may share the device (and the table's cached plan)
-            self.plan = engine.VoigtPlan(self.lines, nL, grid.n)
-            mk = lambda OD: engine.TudRunner(self.lines, grid, Z, n_layers=nL, Altitudes=Z_s, theta_r=theta_r, N_angle=N_angle,
-                                             returnOD=returnOD, OD=OD, plan=self.plan)
-            self.runs = [mk(None)]
-            self.runs.append(mk(self.runs[0].OD))  # the layer optical depths are consumed on the compute stream: one buffer
+            # two runners, each with a stream, per-(line, layer) records and an optical-depth buffer of its own (another
+            # pipeline may share the device and the table's cached plan): the prologue and TUD pass of one atmosphere overlap
+            # the line-sum of the next (engine.TudPipelines)
+            self.computes = [torch.cuda.Stream(), torch.cuda.Stream()]
+            self.plans = [engine.VoigtPlan(self.lines, nL, grid.n) for _ in range(2)]
+            self.runs = []
+            for st, pl in zip(self.computes, self.plans):
+                with torch.cuda.stream(st):
+                    self.runs.append(engine.TudRunner(self.lines, grid, Z, n_layers=nL, Altitudes=Z_s, theta_r=theta_r, N_angle=N_angle,
+                                                      returnOD=returnOD, plan=pl))
         self.busy = [None, None]  # copy-done event of each runner's outputs
         self.staging = _hostio.Staging(depth=2)
         self.k = 0
@@ -322,9 +325,9 @@ class _TudPipeline:
         j = self.k & 1
         self.k += 1
         run = self.runs[j]
-        with torch.cuda.device(self.dev), torch.cuda.stream(self.compute):
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.computes[j]):
             if self.busy[j] is not None:
-                self.compute.wait_event(self.busy[j])  # its previous outputs have left the device
+                self.computes[j].wait_event(self.busy[j])  # its previous outputs have left the device
             tau, Lu, Ld = run.run(np.asarray(a["Ts"], dtype=np.float64), np.asarray(a["Ps"], dtype=np.float64),
                                   np.asarray(a["PLs"], dtype=np.float64), np.asarray(a["MFs_VAL"], dtype=np.float64), ID)
             Xr = None
@@ -346,7 +349,8 @@ class _TudPipeline:
     def close(self):
         with torch.cuda.device(self.dev):
             torch.cuda.synchronize()
-            self.plan.close()
+            for pl in self.plans:
+                pl.close()
 
 
 def compute_TUD_batch(Xmin, Xmax, atmospheres, opts=options, reduce=None, devices=None, out_dtype=np.float64, **kwargs):
