@@ -43,6 +43,9 @@
 #ifndef RTX_SC_ASYM
 #define RTX_SC_ASYM 1
 #endif
+#ifndef RTX_SC_OUTER
+#define RTX_SC_OUTER 1  // outer band rows of y < 1 lines in fp32 (0: fp64 on every band row, as in round 2)
+#endif
 #ifndef RTX_SC_ROWS
 #define RTX_SC_ROWS 16  // rows of 64 points per tile (1024 points, 4 KiB of LDS per wave copy). Round 2, after the tile level went: 8 -> 2.38 ms, 10 -> 2.38, 12 -> 2.32, 14 -> 2.29, 16 -> 2.24, 18 -> 2.34, 20 -> 2.32 (C3, prologue + line-sum)
 #endif
@@ -128,7 +131,10 @@ __device__ __forceinline__ void band_row(const ScArgs& a, const LineRec64* __res
   float x;
   farwing(u, q, x, num, rden);
   const bool in_band = fabsf(u) <= zw_f;
-  if (MODE == 2 && small_y) {
+  // MODE 2, Doppler-dominated line: a row none of whose lanes is closer than |x| = 5.5 to the centre -- most rows of the
+  // wide bands at high wavenumbers -- leaves fp64: the 12-term asymptotic series in fp32 (rtx_voigt_math.h: asymK_re)
+  const bool outer_row = MODE == 2 && small_y && RTX_SC_OUTER && __ballot(fabsf(x) < 5.5f) == 0ull;
+  if (MODE == 2 && small_y && !outer_row) {
     // Doppler-dominated line: the reference's switch and its Weideman value in fp64 on every lane of the row; lanes
     // outside |x| + y < 15 keep the far-wing value
     const LineRec64 Q = rec64[slot];
@@ -138,7 +144,7 @@ __device__ __forceinline__ void band_row(const ScArgs& a, const LineRec64* __res
       num = (float)(Q.A * weideman_re<double>(x64, Q.y));
       rden = 1.0f;
     }
-  } else if (CORE64 ? small_y : !small_y) {
+  } else if (CORE64 ? small_y : (!small_y || outer_row)) {
     // hum1_wei's switch |x|+y < 15 (:9840): fp32 decides unless a lane sits within 2e-3 of it; those
     // lanes repeat the test exactly as the reference forms it, in fp64: x = -Im Z1 = -((sg0 - sg)*cte)
     const float s32 = fabsf(x) + q.y;
@@ -162,7 +168,8 @@ __device__ __forceinline__ void band_row(const ScArgs& a, const LineRec64* __res
       // the outer rows of a wide band -- takes the series too; Weideman itself only for the rows around the centre.
       const bool series = RTX_SC_ASYM && (q.y >= 6.0f || __ballot(wz && fmaf(x, x, q.y * q.y) < 64.0f) == 0ull);
       if (wz) {
-        if (series) num = q.A * asym6_re(x, q.y);
+        if (MODE == 2 && outer_row) num = q.A * asymK_re<12>(x, q.y);
+        else if (series) num = q.A * asym6_re(x, q.y);
         else num = q.A * weideman_re<float>(x, q.y);
         rden = 1.0f;
       }

@@ -420,3 +420,36 @@ def test_column_signature_is_nan_safe_and_sees_edits():
     data = hapi.LOCAL_TABLE_CACHE.pop("sigtest")["data"]
     assert isinstance(data["nu"], np.ndarray) and isinstance(data["molec_id"], np.ndarray) and isinstance(data["global_upper_quanta"], list)
     assert data["nu"] is not a
+
+
+def test_outer_band_series_matches_weideman_for_doppler_lines():
+    """csrc/rtx_voigt_math.h: asymK_re<12>, the fp32 12-term asymptotic series the line-sum uses on the outer band rows
+    (every lane |x| >= 5.5) of Doppler-dominated (y < 1) lines instead of the fp64 Weideman polynomial. Restated in NumPy
+    float32 and compared with the oracle's hum1_wei (the reference's Weideman-24 value) in the parity metric -- error over
+    max(value, 1e-3 of the line's peak, w(0) = 1) -- over 1e-5 <= y < 1 and 5.5 <= |x| < 15."""
+    from oracle import cpu_ref as ref
+    f = np.float32
+
+    def asym12(x, y):
+        x = x.astype(f)
+        y = f(y)
+        r2 = x * x + y * y
+        inv = f(1) / r2
+        zr, zi = x * inv, -y * inv
+        ur, ui = zr * zr - zi * zi, f(2) * zr * zi
+        c = [1.0]
+        for k in range(1, 12):
+            c.append(c[-1] * (2 * k - 1) / 2.0)
+        pr, pi = np.full_like(x, f(c[11])), np.zeros_like(x)
+        for k in range(10, -1, -1):
+            pr, pi = pr * ur - pi * ui + f(c[k]), pr * ui + pi * ur
+        return (-f(0.5641895835477563) * (zr * pi + zi * pr)).astype(np.float64)
+
+    worst = 0.0
+    for y in (1e-5, 1e-4, 1e-3, 1e-2, 0.05, 0.2, 0.5, 0.99):
+        for sgn in (1.0, -1.0):
+            x = sgn * np.linspace(5.5, 15.0, 6001)
+            x = x[np.abs(x) + y < 15.0]
+            w = ref.hum1_wei(x, np.full_like(x, y))[0]
+            worst = max(worst, float(np.max(np.abs(asym12(x, y) - w) / np.maximum(w, 1e-3))))
+    assert worst <= 1e-6, worst
