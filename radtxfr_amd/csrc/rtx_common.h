@@ -148,6 +148,7 @@ struct rtx_prep {
   LineRec* rec;        // [max_layers][n_lines]
   LineRec64* rec64;    // [max_layers][n_lines]
   int* ic;             // [n_lines] local grid index nearest the UNSHIFTED centre (sorted)
+  int2* win;           // [max_layers][n_lines] the records' windows (lo, hi) on their own: what tile_ranges_kernel scans (8 of a record's 48 bytes)
   int* maxhw;          // [max_layers] max window half-width in grid points (+margin)
   int2* ranges;        // [max_layers][max_tiles] candidate line range per line-sum tile
   int* smally;         // [max_layers] set when a line of that layer has a Weideman band with y < 1

@@ -151,6 +151,7 @@ extern "C" int rtx_prep_free(rtx_prep* P) {
   if (P->rec) (void)hipFree(P->rec);
   if (P->rec64) (void)hipFree(P->rec64);
   if (P->ic) (void)hipFree(P->ic);
+  if (P->win) (void)hipFree(P->win);
   if (P->maxhw) (void)hipFree(P->maxhw);  // smally lives in the same allocation
   if (P->env) (void)hipFree(P->env);
   if (P->ranges) (void)hipFree(P->ranges);
@@ -180,6 +181,7 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
   hipError_t e = hipMalloc((void**)&P->rec, nrec * sizeof(LineRec));
   if (e == hipSuccess) e = hipMalloc((void**)&P->rec64, nrec * sizeof(LineRec64));
   if (e == hipSuccess) e = hipMalloc((void**)&P->ic, sizeof(int) * (size_t)(lines->n > 0 ? lines->n : 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&P->win, nrec * sizeof(int2));
   if (e == hipSuccess) e = hipMalloc((void**)&P->maxhw, (2 * (size_t)max_layers + 1) * sizeof(int));  // [maxhw | smally | n_items]: one memset per prologue
   if (e == hipSuccess) { P->smally = P->maxhw + max_layers; P->n_items = P->maxhw + 2 * max_layers; }
   if (e == hipSuccess) e = hipMalloc((void**)&P->env, sizeof(double) * P->env_cap);
@@ -217,6 +219,7 @@ struct PrepArgs {
   LineRec* rec;
   LineRec64* rec64;
   int* ic;
+  int2* win;
   int* maxhw;
   int* smally;
 };
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
       r.a = 0.f; r.c = 0.f; r.b1 = 0.f; r.b0 = 1.f; r.Ay = 0.f; r.Ay0 = 0.f; r.y = 15.f; r.A = 0.f;
       r.i0 = sat_local(gi0 - g.offset, g.n); r.lo = 0; r.hi = 0; r.zw = 0;
       a.rec[o] = r;
+      a.win[o] = make_int2(0, 0);
       if (!pre_dropped && ghi > glo) {
         double hw = ceil(W / g.step) + 2.0;
         my_hw = hw > 1.0e9 ? 1000000000 : (int)hw;
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     const size_t o = (size_t)k * (size_t)a.n_lines + (size_t)l;
     a.rec[o] = r;
     a.rec64[o] = r64;
+    a.win[o] = make_int2(lo, hi);
     if (a.profile == RTX_PROFILE_SDVOIGT) {
       // Gamma2 = sum_species abun * SD_species * p/pref * gamma_species(Tref) (misc/hapi.py:10884-10890); Shift2 = 0
       double Gam2 = 0.0;
@@ -532,7 +537,7 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
   a.dil_air = dil_air; a.dil_self = dil_self; a.omega_wing = omega_wing; a.omega_wing_hw = omega_wing_hw;
   a.thresh = intensity_threshold; a.scale = scale; a.profile = profile;
   a.g = to_dev(grid);
-  a.rec = P->rec; a.rec64 = P->rec64; a.ic = P->ic; a.maxhw = P->maxhw; a.smally = P->smally;
+  a.rec = P->rec; a.rec64 = P->rec64; a.ic = P->ic; a.win = P->win; a.maxhw = P->maxhw; a.smally = P->smally;
   dim3 grd((unsigned)((L->n + 255) / 256), (unsigned)n_layers);
   if (env_args) hipLaunchKernelGGL(line_prep_kernel<true>, grd, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(line_prep_kernel<false>, grd, dim3(256), 0, st, a);

@@ -14,7 +14,7 @@
 struct RangeArgs {
   const int* ic;
   const int* maxhw;
-  const LineRec* rec;
+  const int2* win;
   long long n_lines;
   int n_tiles, tile, n_layers, n_steps;
   long long n;
@@ -38,25 +38,25 @@ struct RangeArgs {
 #define RNG_G 16
 __device__ __forceinline__ unsigned group_bits(unsigned long long b, int lane) { return (unsigned)(b >> (lane & 48)) & 0xffffu; }
 
-// number of elements of the sorted ic[lo, hi) that are < v (STRICT) or <= v, by the 16 lanes of a group. n_steps is
-// wave-uniform (host: enough for n_lines); a group that has converged early repeats a no-op.
+// One step of the 17-ary search for the number of elements of the sorted ic[lo, hi) that are < v (STRICT) or <= v: the 16
+// lanes of a group probe 16 positions at once. A group that has converged repeats a no-op.
 template <bool STRICT>
-__device__ __forceinline__ long long group_bound(const int* __restrict__ ic, long long lo, long long hi, long long v, int sub, int lane,
-                                                 int n_steps) {
-  for (int it = 0; it < n_steps; ++it) {
-    const long long width = hi - lo;
-    const long long stride = (width + RNG_G) / (RNG_G + 1);  // >= 1 while width > 0
-    const long long p = lo + (long long)(sub + 1) * stride - 1;
-    const bool pred = width > 0 && p < hi && (STRICT ? (long long)ic[p] < v : (long long)ic[p] <= v);
-    const int c = __popc(group_bits(__ballot(pred), lane));  // the predicate is monotone along the probes
-    if (width > 0) {
-      // probe c was evaluated and failed when it lies inside the bracket: the answer is <= its position
-      const long long cap = lo + (long long)(c + 1) * stride - 1;
-      if (c < RNG_G && cap < hi) hi = cap;
-      lo += (long long)c * stride;  // probes 0 .. c-1 passed: the answer is > their positions
-    }
+__device__ __forceinline__ void bound_step(const int* __restrict__ ic, int& lo, int& hi, int v, int sub, int lane) {
+  // 32-bit arithmetic throughout (n_lines <= 2e9; a 64-bit division by 17 is a hundred-instruction sequence on this chip,
+  // the unsigned 32-bit one a multiply-high and a shift)
+  const unsigned width = (unsigned)(hi - lo);
+  const int stride = (int)((width + RNG_G) / (unsigned)(RNG_G + 1));  // >= 1 while width > 0
+  const long long pl = (long long)lo + (long long)(sub + 1) * stride - 1;
+  const bool inside = width > 0 && pl < (long long)hi;
+  const int p = inside ? (int)pl : lo;
+  const bool pred = inside && (STRICT ? ic[p] < v : ic[p] <= v);
+  const int c = __popc(group_bits(__ballot(pred), lane));  // the predicate is monotone along the probes
+  if (width > 0) {
+    // probe c was evaluated and failed when it lies inside the bracket: the answer is <= its position
+    const long long cap = (long long)lo + (long long)(c + 1) * stride - 1;
+    if (c < RNG_G && cap < (long long)hi) hi = (int)cap;
+    lo += c * stride;  // probes 0 .. c-1 passed: the answer is > their positions
   }
-  return lo;
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
@@ -68,35 +68,43 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(RangeArgs a) {
   long long ib = ia + a.tile;
   if (ib > a.n) ib = a.n;
   const long long hw = a.maxhw[k];
-  const long long l0 = group_bound<true>(a.ic, 0, live ? a.n_lines : 0, ia - hw, sub, lane, a.n_steps);
-  const long long l1 = group_bound<false>(a.ic, l0, live ? a.n_lines : 0, ib - 1 + hw, sub, lane, a.n_steps);
-  const LineRec* __restrict__ rec = a.rec + (size_t)k * (size_t)a.n_lines;
-  long long first = l1, last = l1;  // nothing reaches: empty range
+  // both searches in one loop: their loads are independent, so the chain of dependent memory round trips -- what this
+  // kernel's time is made of -- is n_steps long, not twice that
+  int l0 = 0, h0 = live ? (int)a.n_lines : 0, l1 = 0, h1 = h0;
   {
-    long long base = l0;
-    bool done = base >= l1;
-    while (__ballot(!done)) {
-      const long long s = base + sub;
-      const bool reach = !done && s < l1 && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
-      const unsigned m = group_bits(__ballot(reach), lane);
-      if (!done) {
-        if (m) { first = base + __builtin_ctz(m); done = true; }
-        else { base += RNG_G; done = base >= l1; }
-      }
+    // the centre indices are clamped to +-(1e8 + n) by the prologue, so clamping the two search keys to int32 changes nothing
+    const long long v0 = ia - hw, v1 = ib - 1 + hw;
+    const int k0 = (int)(v0 < -2147483647LL ? -2147483647LL : v0), k1 = (int)(v1 > 2147483647LL ? 2147483647LL : v1);
+    for (int it = 0; it < a.n_steps; ++it) {
+      bound_step<true>(a.ic, l0, h0, k0, sub, lane);
+      bound_step<false>(a.ic, l1, h1, k1, sub, lane);
     }
   }
-  if (first < l1) {
-    long long top = l1;
-    bool done = false;
-    while (__ballot(!done)) {
-      const long long s = top - 1 - sub;
-      const bool reach = !done && s >= first && (long long)rec[s].hi > ia && (long long)rec[s].lo < ib;
-      const unsigned m = group_bits(__ballot(reach), lane);
-      if (!done) {
-        if (m) { last = top - __builtin_ctz(m); done = true; }
-        else { top -= RNG_G; done = top <= first; }  // cannot happen before `first` itself is met
+  if (l1 < l0) l1 = l0;
+  const int2* __restrict__ win = a.win + (size_t)k * (size_t)a.n_lines;
+  long long first = l1, last = l1;  // nothing reaches: empty range
+  {
+    // the trim from both ends, likewise in one loop: 16 candidates' windows from the front and 16 from the back per step
+    int base = l0, top = l1;
+    bool done_f = base >= l1, done_b = done_f;
+    while (__ballot(!done_f || !done_b)) {
+      const int sf = base + sub, sb = top - 1 - sub;
+      int2 wf = make_int2(0, 0), wb = wf;  // (lo, hi); an empty window reaches nothing
+      if (!done_f && sf < l1) wf = win[sf];
+      if (!done_b && sb >= l0) wb = win[sb];
+      const bool rf = (long long)wf.y > ia && (long long)wf.x < ib && wf.y > wf.x;
+      const bool rb = (long long)wb.y > ia && (long long)wb.x < ib && wb.y > wb.x;
+      const unsigned mf = group_bits(__ballot(rf), lane), mb = group_bits(__ballot(rb), lane);
+      if (!done_f) {
+        if (mf) { first = base + __builtin_ctz(mf); done_f = true; }
+        else { base += RNG_G; done_f = base >= l1; }
+      }
+      if (!done_b) {
+        if (mb) { last = top - __builtin_ctz(mb); done_b = true; }
+        else { top -= RNG_G; done_b = top <= l0; }
       }
     }
+    if (first >= l1) last = first = l1;  // no line of the bracket reaches the tile
   }
   if (live && sub == 0) {
     // a hot tile keeps its first RTX_SPLIT_PART candidates; every further part becomes an item of the work list (consecutive
@@ -136,9 +144,10 @@ static void launch_tile_ranges(const rtx_prep* P, const rtx_grid* grid, int n_la
   RangeArgs ra;
   const bool cut = split && P->split_bound > 0 && P->items;
   ra.items = cut ? P->items : nullptr; ra.n_items = P->n_items; ra.items_cap = P->items_cap;
-  ra.ic = P->ic; ra.maxhw = P->maxhw; ra.rec = P->rec; ra.n_lines = P->n_lines; ra.n_tiles = n_tiles; ra.tile = tile;
+  ra.ic = P->ic; ra.maxhw = P->maxhw; ra.win = P->win; ra.n_lines = P->n_lines; ra.n_tiles = n_tiles; ra.tile = tile;
   ra.n_layers = n_layers; ra.n = grid->n; ra.ranges = P->ranges;
-  int n_steps = 2;  // 17-ary search: each step divides the bracket by 17; two more to finish the last <= 17 elements
+  int n_steps = 1;  // 17-ary search: each step divides the bracket by 17 (rounded up), one more finishes the last <= 16 elements
+                    // (the step count is checked against bisect for every size class in a NumPy restatement: tests/test_host.py)
   for (long long w = P->n_lines; w > 0; w /= (RNG_G + 1)) ++n_steps;
   ra.n_steps = n_steps;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((n_tiles * RNG_G + 255) / 256, n_layers), dim3(256), 0, st, ra);

@@ -453,3 +453,41 @@ def test_outer_band_series_matches_weideman_for_doppler_lines():
             w = ref.hum1_wei(x, np.full_like(x, y))[0]
             worst = max(worst, float(np.max(np.abs(asym12(x, y) - w) / np.maximum(w, 1e-3))))
     assert worst <= 1e-6, worst
+
+
+def test_range_search_step_count():
+    """csrc/rtx_voigt.hip: bound_step / tile_ranges_kernel. The 17-ary search of 16 lanes (16 probes per step; the bracket
+    shrinks to at most its stride) restated in Python: with n_steps = 1 + the number of times n can be divided by 17 before
+    reaching 0 -- what launch_tile_ranges passes -- it returns bisect_left / bisect_right for every size class."""
+    import bisect
+    G = 16
+
+    def search(ic, v, strict, n_steps):
+        lo, hi = 0, len(ic)
+        for _ in range(n_steps):
+            width = hi - lo
+            if width <= 0:
+                continue
+            stride = (width + G) // (G + 1)
+            c = 0
+            for sub in range(G):
+                p = lo + (sub + 1) * stride - 1
+                if p < hi and (ic[p] < v if strict else ic[p] <= v):
+                    c += 1
+            cap = lo + (c + 1) * stride - 1
+            if c < G and cap < hi:
+                hi = cap
+            lo += c * stride
+        return lo
+
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 16, 17, 18, 288, 289, 290, 4913, 4914, 20000):
+        steps, w = 1, n
+        while w > 0:
+            w //= 17
+            steps += 1
+        for _ in range(20):
+            ic = np.sort(rng.integers(-50, 3 * n + 50, n)).tolist()
+            for v in rng.integers(-60, 3 * n + 60, 6).tolist() + [ic[0], ic[-1], ic[n // 2]]:
+                assert search(ic, v, True, steps) == bisect.bisect_left(ic, v)
+                assert search(ic, v, False, steps) == bisect.bisect_right(ic, v)

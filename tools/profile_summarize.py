@@ -25,6 +25,12 @@ shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench_n1.
 stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
 assert stats, "no kernel_stats.csv"
 shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+stats_p = glob.glob(os.path.join(src, "trace_pipelined", "**", "*_kernel_stats.csv"), recursive=True)
+if stats_p:
+    shutil.copy(stats_p[0], os.path.join(dst, f"{tag}_bench_kernel_stats_pipelined.csv"))
+for extra in ("bench_prof.json", "bench_prof_pipelined.json"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
 
 per = {}
 lines = []
@@ -74,7 +80,9 @@ if hit and "SQ_INSTS_VALU" in per[hit[0]]:
     with open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out))
-for extra in ("rehearsal_gloo2.json", "time_c3_thin.txt", "time_overhead.txt", "time_fused_bound.txt"):
+for extra in ("rehearsal_gloo2.json", "time_c3_thin.txt", "time_overhead.txt", "time_fused_bound.txt", "shard_balance.txt", "time_pipeline.txt",
+              "time_c3_uniform.txt", "time_c3_clustered.txt", "tile_spread_uniform.txt", "tile_spread_clustered.txt", "time_dropin.txt",
+              "time_xs.txt", "time_xs_round2_kernel.txt", "ubench_crosslayer.txt", "c4_timing.txt", "c5_timing.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read()[:1500])
