@@ -338,11 +338,20 @@ class _TudPipeline:
                 nr = tau.shape[0]
                 t = self.staging.stage([red[:nr], red[nr:2 * nr], red[2 * nr:]], stream=self.side)
             else:
+                # full float64 spectra: zero-copy pinned blocks while the module's cap allows (a short batch then costs no host
+                # work at all), the pinned staging ring + threaded widening into pageable arrays beyond it
+                got = _hostio.rows_to_pinned_f64([tau, Lu, Ld[None, :]], stream=self.side) if full_dtype == np.float64 else None
+                if got is not None:
+                    self.busy[j] = got[1]
+                    return ("pinned", got[0], got[1]), Xr
                 t = self.staging.stage([tau, Lu, Ld[None, :]], stream=self.side)
             self.busy[j] = t[3]
         return t, Xr
 
     def finish(self, ticket, dtype):
+        if ticket[0] == "pinned":
+            ticket[2].synchronize()
+            return ticket[1]
         with torch.cuda.device(self.dev):
             return self.staging.collect(ticket, dtype)
 
@@ -369,8 +378,10 @@ def compute_TUD_batch(Xmin, Xmax, atmospheres, opts=options, reduce=None, device
     pipelines sharing a device). None = the current device. Results come back in input order and are bit-identical to
     per-call compute_TUD whatever the devices.
     out_dtype: float64 (the reference's) or float32 (half the host work when full spectra are kept).
-    Returns a list of (X, tau, Lu, Ld) with the shapes compute_TUD gives (X_out instead of X when reduce is set); the
-    arrays are ordinary pageable NumPy arrays (float32 crosses PCIe into a reusable pinned ring, a host thread pool widens)."""
+    Returns a list of (X, tau, Lu, Ld) with the shapes compute_TUD gives (X_out instead of X when reduce is set). Full
+    float64 spectra are views of page-locked blocks while fewer than _hostio.PINNED_RESULT_CAP bytes are lent out (1 GiB:
+    the first eight C3-sized results), ordinary pageable arrays beyond that and for every other output (float32 crosses
+    PCIe into a reusable pinned ring, a host thread pool widens: host-memory bound, ~10 ms per 132 MB result)."""
     o = dict(opts)
     o.update(kwargs)
     if o["save"]:
