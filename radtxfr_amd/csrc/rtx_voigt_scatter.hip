@@ -817,6 +817,9 @@ int rtx_voigt_sum_scatter(const rtx_prep* P, const rtx_grid* grid, int n_layers,
   const long long n_tiles_ll = (grid->n + TILE - 1) / TILE;
   if (n_tiles_ll > P->max_tiles) RTX_FAIL("grid shard of %lld points exceeds the prep capacity", (long long)grid->n);
   const int n_tiles = (int)n_tiles_ll;
+  // the work list of hot-tile parts is rebuilt by every call (a caller may sum twice after one prologue, e.g. once per
+  // output precision): its counter starts from zero each time
+  if (nodal && P->split_bound > 0 && P->items) RTX_HIP(hipMemsetAsync(P->n_items, 0, sizeof(int), st));
   launch_ranges(P, grid, n_layers, n_tiles, TILE, st, nodal);  // the point-by-point cross-check takes every tile whole
   RTX_LAUNCH_CHECK();
   ScArgs a;
