@@ -191,6 +191,14 @@ def test_clustered_table_full_grid_properties():
     assert lib.rtx_prep_split_bound(lines.plan(32, grid.n)._h) > 100
     OD_b = engine.optical_depths(lines, grid, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
     assert torch.equal(OD, OD_b), "not bit-reproducible from run to run"
+    # rtx_voigt_sum twice after ONE prologue (the C ABI allows it): the hot-tile work list is rebuilt, not appended to
+    import ctypes as C
+    plan = lines.plan(32, grid.n)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    OD_c = torch.empty_like(OD)
+    _lib.check(lib.rtx_voigt_sum(plan._h, grid.byref(), 32, C.c_void_p(OD_c.data_ptr()), None, grid.n, st))
+    assert torch.equal(OD, OD_c), "a second sum after the same prologue differs"
+    del OD_c
     uni = engine.LineTable(synthetic.subset_table(synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0), 900.0, 1100.0))
     g_u = engine.Grid(500.0, 6000.0, 5500000).shard(450 * 1024, 64 * 1024)
     engine.optical_depths(uni, g_u, a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
