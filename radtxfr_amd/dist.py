@@ -94,7 +94,9 @@ def all_gather_spectra(local, n_total, group=None, offs=None):
     C = local.shape[0]
     send = local if n_loc == per else torch.nn.functional.pad(local, (0, per - n_loc))
     send = send.contiguous().view(-1)  # flat buffers: accepted by both the RCCL and the gloo backends
-    recv = _all_gather_flat(send, world, group).view(world, C, per)
+    from .engine import trace_range
+    with trace_range("all_gather_spectra"):
+        recv = _all_gather_flat(send, world, group).view(world, C, per)
     if np.all(lens[:-1] == per):  # equal chunks, ragged tail only: one strided view
         return recv.permute(1, 0, 2).reshape(C, world * per)[:, :n_total]
     return torch.cat([recv[r, :, :int(lens[r])] for r in range(world)], dim=1)

@@ -23,6 +23,24 @@ def volumeConcentration(p, T):
     return (p / 9.869233e-7) / (CBOLTS * T)
 
 
+class trace_range:
+    """roctx range around a stage (tracing hook), visible in `rocprofv3 --marker-trace`: enabled with
+    RADTXFR_ROCTX=1, otherwise a no-op that costs one attribute test. torch.cuda.nvtx maps to roctx on ROCm."""
+    enabled = bool(int(__import__("os").environ.get("RADTXFR_ROCTX", "0") or 0))
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if trace_range.enabled:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if trace_range.enabled:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise _lib.RtxError("no HIP device visible: radtxfr_amd has no CPU fallback (torch.cuda.is_available() is False)")
@@ -455,12 +473,13 @@ class TudRunner:
         env[2 * nL + 2 * nS * nL:] = mass
         base = env.ctypes.data
         vp = C.c_void_p
-        _lib.check(self.lib.rtx_compute_tud(
-            self.plan._h, lines._h, self.grid.byref(), nL, vp(base), vp(base + 8 * nL), vp(base + 16 * nL),
-            vp(base + 8 * (2 * nL + nS * nL)), vp(base + 8 * (2 * nL + 2 * nS * nL)), 1.0, 0.0, 0.0, 50.0, 0.0,
-            self.shape[0], self.mask.ctypes.data_as(vp), self.shape[1], self.mu.ctypes.data_as(vp), self.n_down, self.N_angle,
-            self.returnOD, vp(self.OD.data_ptr()), self.OD.stride(0), self._ptrs[0], self._ptrs[1], self._ptrs[2], self._ld_out,
-            _stream_ptr()))
+        with trace_range("rtx_compute_tud"):
+            _lib.check(self.lib.rtx_compute_tud(
+                self.plan._h, lines._h, self.grid.byref(), nL, vp(base), vp(base + 8 * nL), vp(base + 16 * nL),
+                vp(base + 8 * (2 * nL + nS * nL)), vp(base + 8 * (2 * nL + 2 * nS * nL)), 1.0, 0.0, 0.0, 50.0, 0.0,
+                self.shape[0], self.mask.ctypes.data_as(vp), self.shape[1], self.mu.ctypes.data_as(vp), self.n_down, self.N_angle,
+                self.returnOD, vp(self.OD.data_ptr()), self.OD.stride(0), self._ptrs[0], self._ptrs[1], self._ptrs[2], self._ld_out,
+                _stream_ptr()))
         return self.tau, self.Lu, self.Ld
 
 
