@@ -386,7 +386,9 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     r64.sg0 = sg0; r64.cte = cte; r64.y = y; r64.A = A;
     const size_t o = (size_t)k * (size_t)a.n_lines + (size_t)l;
     a.rec[o] = r;
+#ifndef RTX_PREP_ABLATE_REC64
     a.rec64[o] = r64;
+#endif
     a.win[o] = make_int2(lo, hi);
     if (a.profile == RTX_PROFILE_SDVOIGT) {
       // Gamma2 = sum_species abun * SD_species * p/pref * gamma_species(Tref) (misc/hapi.py:10884-10890); Shift2 = 0

@@ -1004,12 +1004,55 @@ __global__ __launch_bounds__(256) void tud_g_snap_kernel(TudArgs a) {
   };
   snapshot(0);
   bool down_live = nd > 0;  // wave-uniform
+  // as in tud_g_kernel: prefetch pointers bumped, and a chunk whose layers all count for the upwelling and the downwelling
+  // runs unrolled with static offsets (the layer loop is bound by the CU's one scalar unit)
+  const size_t bump = (size_t)TUD_STAGE * (size_t)a.ld;
+  const float* pf[TUD_STAGE];
+#pragma unroll
+  for (int t = 0; t < TUD_STAGE; ++t) pf[t] = od_col + (size_t)(TUD_STAGE + t) * (size_t)a.ld;
   for (int kc = 0; kc < nL; kc += TUD_STAGE) {
 #pragma unroll
     for (int t = 0; t < TUD_STAGE; ++t) s_stage[t][threadIdx.x] = nxt[t];
+    if (kc + 2 * TUD_STAGE <= nL) {
 #pragma unroll
-    for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = od_col[(size_t)(kc + TUD_STAGE + t < nL ? kc + TUD_STAGE + t : nL - 1) * a.ld];
+      for (int t = 0; t < TUD_STAGE; ++t) nxt[t] = *pf[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < TUD_STAGE; ++t)
+        if (kc + TUD_STAGE + t < nL) nxt[t] = *pf[t];
+    }
+#pragma unroll
+    for (int t = 0; t < TUD_STAGE; ++t) pf[t] += bump;
     const int k_hi = kc + TUD_STAGE < nL ? kc + TUD_STAGE : nL;
+    if (PN && k_hi == kc + TUD_STAGE && k_hi <= cnt_max && k_hi <= nd && k_hi < 64) {
+      const unsigned snap_chunk = (unsigned)(snap_lo >> (kc + 1));  // bit t: some altitude's column ends after layer kc + t
+#pragma unroll
+      for (int t = 0; t < TUD_STAGE; ++t) {
+        const float od = s_stage[t][threadIdx.x];
+        const int kk = kc + t;
+        const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(PNd.c0), kk));
+        const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(PNd.c1), kk));
+        const float q2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(PNd.c2), kk));
+        const float B = fmaf(fmaf(q2, PNd.t, q1), PNd.t, q0);  // planck_nodes_eval(PNd, kc + t), kc + t < 64
+        s_run += od;
+#pragma unroll
+        for (int m = 0; m < NMU; ++m) {
+          if (NMU == 1 || m < n_mu) {
+            const float y = od * cm[m];
+            Lu[m] = (y > -TUD_THIN_Y) ? fmaf(em_thin(y), B - Lu[m], Lu[m]) : fmaf(__builtin_amdgcn_exp2f(y), Lu[m] - B, B);
+          }
+        }
+        if ((snap_chunk >> t) & 1u) snapshot(kk + 1);
+        if (down_live) {
+          S += (double)od;
+          const double g = tudg_eval(s_g, S);
+          acc = fmaf(B, (float)(g_prev - g), acc);
+          g_prev = g;
+          if (__ballot(g > g_floor) == 0ull) down_live = false;
+        }
+      }
+      continue;
+    }
     for (int k = kc; k < k_hi; ++k) {
       const float od = s_stage[k - kc][threadIdx.x];
       const bool up = k < cnt_max, dn = down_live && k < nd;  // wave-uniform
@@ -1219,7 +1262,11 @@ extern "C" int rtx_tud(const float* OD, int64_t ld, const rtx_grid* grid, int n_
       if (pn) hipLaunchKernelGGL(tud_g_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(tud_g_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else if (prefix) {
-      if (pn) hipLaunchKernelGGL((tud_g_snap_kernel<TUD_MAX_MU, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      // one slant path (the reference's main caller: 9 altitudes, nadir): the instantiation without the per-slant guards
+      if (n_mu == 1) {
+        if (pn) hipLaunchKernelGGL((tud_g_snap_kernel<1, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tud_g_snap_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      } else if (pn) hipLaunchKernelGGL((tud_g_snap_kernel<TUD_MAX_MU, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((tud_g_snap_kernel<TUD_MAX_MU, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     else hipLaunchKernelGGL(tud_g_pairs_kernel<TUDG_PB>, dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -697,3 +697,35 @@ def reduce_resolution(Y, x0, h, n, dX, N=4, window="hanning", x_out=None):
     Ysm = fir_reflect(Y, taps, c)
     out = cubic_resample(Ysm, x0, h, torch.as_tensor(x_out, device=Y.device))
     return x_out, out
+
+
+_REDUCE_PLANS = {}
+
+
+def reduce_resolution_cached(Y, x0, h, n, dX, N=4, window="hanning"):
+    """reduce_resolution on its default output axis, for a stream of spectra on one grid (compute_TUD_batch: every
+    atmosphere of a batch is reduced the same way): the output axis (host and device copies), the symmetrised window taps
+    (a Python loop over the window) and the range checks are made once per (axis, dX, N, window, device) instead of per
+    spectrum -- together they cost more host time than the device needs for the whole atmosphere."""
+    key = (float(x0), float(h), int(n), float(dX), int(N), window, Y.device.index)
+    plan = _REDUCE_PLANS.get(key)
+    if plan is None:
+        sm_factor = int(np.round(dX / h))
+        if sm_factor < 3:
+            raise ValueError(f"reduceResolution: dX/dX_in rounds to {sm_factor}; the window needs at least 3 samples")
+        if window not in _WINDOWS:
+            raise ValueError(f"window must be one of {_WINDOWS}")
+        xa, xb = x0 + sm_factor * h, x0 + (n - sm_factor - 1) * h
+        v = N * (xb - xa) / dX
+        x_out = np.linspace(xa, xb, int(np.ceil(v - 1e-9 * max(1.0, abs(v)))) + 1)
+        margin = (sm_factor + 1) // 2 + 20
+        if x_out.size and (x_out.min() < x0 + margin * h or x_out.max() > x0 + (n - 1 - margin) * h):
+            raise NotImplementedError(
+                f"reduceResolution: output points within {margin} samples of an end of the input axis are not supported "
+                f"(window {sm_factor}: the default X_out needs a window of at least 40 samples)")
+        taps, c = window_taps(sm_factor, window, symmetric=True)
+        if len(_REDUCE_PLANS) > 8:
+            _REDUCE_PLANS.clear()
+        plan = _REDUCE_PLANS[key] = (x_out, torch.as_tensor(x_out, device=Y.device), taps, c)
+    x_out, x_dev, taps, c = plan
+    return x_out, cubic_resample(fir_reflect(Y, taps, c), x0, h, x_dev)

@@ -333,8 +333,8 @@ class _TudPipeline:
             Xr = None
             if reduce is not None:
                 rows = torch.cat([tau, Lu, Ld[None, :]])
-                Xr, red = engine.reduce_resolution(rows, x0, grid.step, grid.n, float(reduce["dX"]), N=reduce.get("N", 4),
-                                                   window=reduce.get("window", "hanning"))
+                Xr, red = engine.reduce_resolution_cached(rows, x0, grid.step, grid.n, float(reduce["dX"]), N=reduce.get("N", 4),
+                                                          window=reduce.get("window", "hanning"))
                 nr = tau.shape[0]
                 t = self.staging.stage([red[:nr], red[nr:2 * nr], red[2 * nr:]], stream=self.side)
             else:
