@@ -11,11 +11,21 @@ from radtxfr_amd import engine, synthetic
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=24)
+ap.add_argument("--shard", default="", help="R/N: rank R's cost-weighted tile-aligned shard of N (with its line subset), as bench.py --gpus N runs it")
 args = ap.parse_args()
 full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
 a = synthetic.c3_atmosphere(32)
-lines = engine.LineTable(full)
 grid = engine.Grid(500.0, 6000.0, 5500000)
+n_pts = 5500000
+if args.shard:
+    from radtxfr_amd import dist as rdist
+    r, nw = (int(t) for t in args.shard.split("/"))
+    offs, reach = rdist.tud_shard_plan(full, 500.0, 6000.0, 5500000, a["Ts"], a["Ps"], nw)
+    grid = grid.shard(int(offs[r]), int(offs[r + 1] - offs[r]))
+    full = synthetic.subset_table(full, grid.x_at(0) - reach, grid.x_at(grid.n - 1) + reach)
+    n_pts = grid.n
+    print(f"shard {r} of {nw}: {grid.n} points, {full['nu'].size} lines")
+lines = engine.LineTable(full)
 for P in (1, 2, 3, 1, 2):
     streams = [torch.cuda.Stream() for _ in range(P)]
     runs = []
@@ -33,7 +43,7 @@ for P in (1, 2, 3, 1, 2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps * 1e3
     chk = [float(r.tau.double().sum()) for r in runs]
-    print(f"{P} pipeline(s): {dt:.3f} ms per atmosphere ({5.5e6 * 32 / dt / 1e-3:.3e} points/s); tau checksums {chk}", flush=True)
+    print(f"{P} pipeline(s): {dt:.3f} ms per atmosphere ({n_pts * 32 / dt / 1e-3:.3e} points/s); tau checksums {chk}", flush=True)
     for r in runs:
         r.plan.close()
     del runs
