@@ -25,7 +25,7 @@ PINNED_RESULT_CAP = int(os.environ.get("RADTXFR_PINNED_RESULT_BYTES", str(1 << 3
 _lent = [0]          # bytes currently handed out
 _owned = [0]         # bytes of every block this module has page-locked (handed out + idle)
 _idle = {}           # (rows, n) -> [pinned float64 tensors] waiting for reuse
-_lent_lock = threading.Lock()
+_lent_lock = threading.RLock()  # re-entrant: a garbage collection under the lock may run a result's finaliser (_release)
 _pool = None
 _CHUNK = 1 << 19  # elements per widening task (2-4 MB)
 

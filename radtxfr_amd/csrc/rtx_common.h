@@ -167,4 +167,5 @@ struct rtx_prep {
   double split_xmin, split_step;
   long long split_off, split_n;
   int split_layers;
+  const void* split_lines;  // the table the bound was made for
 };

@@ -448,7 +448,7 @@ static int rtx_split_bound(rtx_prep* P, const rtx_lines* L, const rtx_grid* g, i
   if (profile == RTX_PROFILE_DOPPLER) gd = (1.1774100225 / 2.99792458e8) * sqrt(1.3806503e-23 / 1.66053873e-27) * sqrt(t_max) * fabs(nu_max) / sqrt(m_min);
   const double W = fmax(omega_wing, fmax(omega_wing_hw * g0, omega_wing_hw * gd)) + 2.0 * g->step;
   const bool same_grid = P->split_xmin == g->xmin && P->split_step == g->step && P->split_off == g->offset && P->split_n == g->n;
-  if (same_grid && P->split_W > 0.0 && W <= P->split_W && n_layers <= P->split_layers) return 0;  // the cached bound covers this call
+  if (same_grid && P->split_lines == (const void*)L && P->split_W > 0.0 && W <= P->split_W && n_layers <= P->split_layers) return 0;  // the cached bound covers this call
   const double Wc = 1.25 * W;
   const int tile = rtx_voigt_tile_points();
   const long long n_tiles = (g->n + tile - 1) / tile;
@@ -478,6 +478,7 @@ static int rtx_split_bound(rtx_prep* P, const rtx_lines* L, const rtx_grid* g, i
   P->split_bound = extra;
   P->split_W = Wc; P->split_xmin = g->xmin; P->split_step = g->step; P->split_off = g->offset; P->split_n = g->n;
   P->split_layers = n_layers;
+  P->split_lines = (const void*)L;
   return 0;
 }
 

@@ -170,7 +170,9 @@ class LocalShardedTud:
 
         sh = LocalShardedTud(devices, Xmin, Xmax, DVOUT, table, Zs, Ts, Ps)   # Ts, Ps: a typical atmosphere, for the plan
         X, tau, Lu, Ld = sh.run(Ts, Ps, PLs, MFs_VAL, MFs_ID)                  # float32 views on devices[0]
-    """
+
+    The tensors run() returns are views of this object's buffers, overwritten by the next run(): copy what must be kept.
+    One sensor altitude and slant path per object (the packed block carries three rows)."""
 
     def __init__(self, devices, Xmin, Xmax, DVOUT, line_table, Zs, Ts, Ps, Altitudes=(500,), theta_r=0.0, N_angle=30, balance=True,
                  backend=-1):
