@@ -76,6 +76,17 @@ def _pinned_block(shape):
     return torch.empty(shape, dtype=torch.float64, pin_memory=True)
 
 
+def lend_block(shape):
+    """(pinned float64 tensor [rows][n], its NumPy view) lent out as a zero-copy result, or None when the cap is reached.
+    The block returns to the idle list when the NumPy array and every view of it have died."""
+    host = _pinned_block((int(shape[0]), int(shape[1])))
+    if host is None:
+        return None
+    arr = host.numpy()
+    weakref.finalize(arr, _release, host, int(shape[0]) * int(shape[1]) * 8)
+    return host, arr
+
+
 def rows_to_pinned_f64(rows, stream=None):
     """float32 device rows [(k_i, n)] -> float64 NumPy views of ONE pinned block (zero-copy path), or None when every
     block the cap allows is still held by earlier results. Returns (arrays, event): valid once `event` has completed."""

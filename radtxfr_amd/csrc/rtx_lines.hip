@@ -202,6 +202,9 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
 #define H_CMASSMOL 1.66053873e-27
 #define H_C2 1.4388028496642257
 #define H_TREF 296.0
+#ifndef RTX_PREP_ABLATE
+#define RTX_PREP_ABLATE 0
+#endif
 #define RTX_ENV_MAX 416  /* doubles of per-layer tables carried in the prologue's kernel arguments (3.3 KB of the 4 KB) */
 
 struct PrepArgs {
@@ -281,7 +284,11 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     double Gamma0 = 0.0, Shift0 = 0.0;
     const double tr = H_TREF / T;
     if (a.dil_air != 0.0) {
+#if RTX_PREP_ABLATE & 1  /* timing experiments only */
+      Gamma0 += a.dil_air * (a.gamma_air[l] * p / 1.0 * (tr * a.n_air[l]));
+#else
       Gamma0 += a.dil_air * (a.gamma_air[l] * p / 1.0 * pow(tr, a.n_air[l]));
+#endif
       const double dp = a.deltap_air ? a.deltap_air[l] : 0.0;
       Shift0 += a.dil_air * ((a.delta_air[l] + dp * (T - H_TREF)) * p / 1.0);
     }
@@ -340,8 +347,13 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     } else {
     // S(T): EnvironmentDependency_Intensity, misc/hapi.py:10169-10175 (SigmaTref/SigmaT = qratio)
     const double el = a.elower[l];
+#if RTX_PREP_ABLATE & 2
+    const double ch = (-H_C2 * el / T) * (1.0 - (-H_C2 * nu / T));
+    const double zn = (-H_C2 * el / H_TREF) * (1.0 - (-H_C2 * nu / H_TREF));
+#else
     const double ch = exp(-H_C2 * el / T) * (1.0 - exp(-H_C2 * nu / T));
     const double zn = exp(-H_C2 * el / H_TREF) * (1.0 - exp(-H_C2 * nu / H_TREF));
+#endif
     const double S = a.sw[l] * eq[(size_t)sp * a.n_layers + k] * ch / zn;
     const bool dropped = pre_dropped || (S < a.thresh);
     if (dropped || hi <= lo) { lo = 0; hi = 0; }

@@ -53,6 +53,7 @@ options = {
     "MF_ID": np.array([]), "MF_VAL": np.array([]),
     "line_table": None,  # replaces "LBLRTM"/"TAPE3": name in hapi.LOCAL_TABLE_CACHE or column dict
     "copy_axis": False,  # True: compute_TUD returns a fresh writable X (the reference's behaviour) instead of a cached read-only one
+    "chunks": None,      # compute_TUD: wavenumber chunks whose device-to-host copies overlap the next chunk's kernels (None: automatic)
     # options for compute_TUD (:172-182)
     "Zs": StdAtmos[:, 1], "Ts": StdAtmos[:, 5], "Ps": StdAtmos[:, 4], "PLs": StdAtmos[:, 3],
     "MFs_VAL": StdAtmos[:, 6:14] * 1e6, "MFs_ID": np.array([1, 2, 3, 4, 5, 6, 7, 22]),
@@ -228,6 +229,64 @@ def _tud_shapes(tau2, Lu2, nZ, nMu):
     return np.ascontiguousarray(tau_), np.ascontiguousarray(Lu_)
 
 
+_SIDE_STREAMS = {}
+
+
+def _compute_tud_chunked(tbl, grid, Z, T, P, PL, MF, ID, Z_s, theta, nA, returnOD, n_chunks):
+    """compute_TUD's device work in n_chunks tile-aligned wavenumber chunks, each chunk's widening and device-to-host copy
+    (side stream) under the next chunk's kernels: a single call is PCIe-bound (132 MB of float64 at C3 size: 2.7 ms against
+    1.9 ms of kernels), and chunks cut on line-sum tile boundaries give the unchunked bits. Returns (tau_h, Lu_h, Ld_h,
+    (nZ, nMu)) as float64 NumPy views of one pinned block, or None when no pinned block can be lent (the caller then takes
+    the plain path)."""
+    from . import _lib, dist as _dist
+    n = grid.n
+    tile = int(_lib.load().rtx_voigt_tile_points())
+    offs = _dist.tile_aligned_bounds(n, n_chunks, tile)
+    nL = T.size
+    nZ, nMu = Z_s.size, np.atleast_1d(theta).size
+    nrow = nZ * nMu
+    lent = _hostio.lend_block((2 * nrow + 1, n))
+    if lent is None:
+        return None
+    host, arr = lent
+    dev = engine.device()
+    tau = torch.empty((nrow, n), dtype=torch.float32, device=dev)
+    Lu = torch.empty_like(tau)
+    Ld = torch.empty((n,), dtype=torch.float32, device=dev)
+    max_len = int(np.diff(offs).max())
+    OD = torch.empty((nL, max_len), dtype=torch.float32, device=dev)
+    plan = tbl.plan(nL, n)
+    side = _SIDE_STREAMS.get(dev.index)
+    if side is None:
+        side = _SIDE_STREAMS[dev.index] = torch.cuda.Stream()
+    done = None
+    for c in range(n_chunks):
+        off, ln = int(offs[c]), int(offs[c + 1] - offs[c])
+        if ln == 0:
+            continue
+        sl = slice(off, off + ln)
+        run = engine.TudRunner(tbl, grid.shard(grid.offset + off, ln), Z, n_layers=nL, Altitudes=Z_s, theta_r=theta, N_angle=nA,
+                               returnOD=returnOD, out=(tau[:, sl], Lu[:, sl], Ld[sl]), OD=OD[:, :ln], plan=plan)
+        run.run(T, P, PL, MF, ID)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            blk = torch.empty((2 * nrow + 1, ln), dtype=torch.float64, device=dev)  # widened on the device
+            blk[:nrow].copy_(tau[:, sl])
+            blk[nrow:2 * nrow].copy_(Lu[:, sl])
+            blk[2 * nrow].copy_(Ld[sl])
+            for r in range(2 * nrow + 1):
+                host[r, sl].copy_(blk[r], non_blocking=True)  # contiguous row segments
+            done = torch.cuda.Event()
+            done.record(side)
+    for t in (tau, Lu, Ld, OD):
+        t.record_stream(side)
+    if done is not None:
+        done.synchronize()
+    return arr[:nrow], arr[nrow:2 * nrow], arr[2 * nrow:], (nZ, nMu)
+
+
 def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
     """Monochromatic transmittance, upwelling and downwelling radiance, signature of :274-392.
 
@@ -262,6 +321,21 @@ def compute_TUD(Xmin, Xmax, opts=options, **kwargs):
         trace.append(time.perf_counter())
     if o.get("copy_axis"):
         X_ = _hostio.copy_threaded(X_)
+    chunks = o.get("chunks")
+    if chunks is None:  # automatic: worth it once the copy of the result outweighs a chunk's fixed costs
+        chunks = 4 if grid.n >= 2000000 else 2 if grid.n >= 500000 else 1
+    if chunks > 1 and mu_s.size <= engine.TUD_MAX_MU and not o["save"]:
+        got = _compute_tud_chunked(tbl, grid, Z, T, P, PL, MF, ID, Z_s, np.asarray(o["theta_r"], dtype=np.float64), nA,
+                                   bool(o["returnOD"]), int(chunks))
+        if got is not None:
+            tau_h, Lu_h, Ld_h, (nZ, nMu) = got
+            if trace:
+                trace.append(time.perf_counter())
+                if trace[-1] - trace[0] > _TRACE * 1e-3:
+                    print("compute_TUD %.1f ms (chunked x%d): options+axis %.2f  table %.2f  kernels + copies %.2f"
+                          % tuple([1e3 * (trace[-1] - trace[0]), chunks] + [1e3 * (b - a) for a, b in zip(trace, trace[1:])]), flush=True)
+            tau_, Lu_ = _tud_shapes(tau_h, Lu_h, nZ, nMu)
+            return X_, tau_, Lu_, Ld_h[0]
     if mu_s.size <= engine.TUD_MAX_MU and not o["save"]:
         # the common case: one call into the library (rtx_compute_tud)
         run = engine.TudRunner(tbl, grid, Z, n_layers=T.size, Altitudes=Z_s, theta_r=np.asarray(o["theta_r"], dtype=np.float64),

@@ -1433,6 +1433,28 @@ def test_compute_tud_batch_devices_and_host_paths(rt):
     lines.close()
 
 
+def test_compute_tud_chunked_equals_unchunked(rt):
+    """compute_TUD in tile-aligned wavenumber chunks (each chunk's device-to-host copy under the next chunk's kernels: a
+    single call is PCIe-bound) returns the unchunked arrays bit for bit -- one and several (altitude, slant) pairs, more
+    chunks than tiles, returnOD -- and the automatic choice (4 chunks from 2 M points) equals chunks=1 on a C3-sized call."""
+    full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
+    lo, hi = 1000.0, 1004.5
+    sub = synthetic.subset_table(full, lo - 12.0, hi + 12.0)
+    a = synthetic.c3_atmosphere(32)
+    a["MFs_VAL"] = a["MFs_VAL"] * 1e-3
+    for extra in (dict(), dict(Altitudes=np.asarray([2.0, 500.0]), theta_r=np.asarray([0.0, 0.7])), dict(returnOD=True)):
+        base = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, chunks=1, **extra, **a)
+        for k in (2, 3, 9):
+            got = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, chunks=k, **extra, **a)
+            assert all(g.shape == b.shape and np.array_equal(g, b) for g, b in zip(got, base)), (extra.keys(), k)
+    big1 = rt.compute_TUD(500.0, 6000.0, DVOUT=0.002, line_table=full, chunks=1, **a)
+    big4 = rt.compute_TUD(500.0, 6000.0, DVOUT=0.002, line_table=full, **a)  # 2.75 M points: automatic = 4 chunks
+    assert big1[1].size == 2750000 and all(np.array_equal(g, b) for g, b in zip(big4, big1))
+    Xr, tau_r, Lu_r, Ld_r = ref.compute_TUD(sub, lo, hi, 0.001, a["Zs"], a["Ts"], a["Ps"], a["PLs"], a["MFs_VAL"], a["MFs_ID"])
+    X, tau, Lu, Ld = rt.compute_TUD(lo, hi, DVOUT=0.001, line_table=sub, chunks=3, **a)
+    assert np.max(np.abs(tau - tau_r)) <= TOL_TAU and rel_err(Lu, Lu_r) <= TOL_L and rel_err(Ld, Ld_r) <= TOL_L
+
+
 def test_compute_tud_save_with_many_slants(rt, tmp_path, monkeypatch):
     """save=True (radiative_transfer.py:374-386) with more slant paths than one rtx_tud launch takes: the slants run in
     blocks and the per-stream downwelling radiances -- independent of the slant -- come from the first block."""
