@@ -239,8 +239,10 @@ __device__ long long grid_bisect_right(const GridDev& g, double v) {
   else k = (long long)floor(t) + 1;
   if (k < 0) k = 0;
   if (k > g.n_total) k = g.n_total;
+#if !(RTX_PREP_ABLATE & 4)
   while (k < g.n_total && grid_x(g, k) <= v) ++k;
   while (k > 0 && grid_x(g, k - 1) > v) --k;
+#endif
   return k;
 }
 
@@ -397,9 +399,11 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     LineRec64 r64;
     r64.sg0 = sg0; r64.cte = cte; r64.y = y; r64.A = A;
     const size_t o = (size_t)k * (size_t)a.n_lines + (size_t)l;
+#if !(RTX_PREP_ABLATE & 8)
     a.rec[o] = r;
 #ifndef RTX_PREP_ABLATE_REC64
     a.rec64[o] = r64;
+#endif
 #endif
     a.win[o] = make_int2(lo, hi);
     if (a.profile == RTX_PROFILE_SDVOIGT) {
