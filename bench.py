@@ -117,8 +117,8 @@ def _latest_profile(suffix):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipelines", type=int, default=3,
                     help="independent pipelines (stream + records + OD buffer each) the atmospheres of the timed loop alternate over "
