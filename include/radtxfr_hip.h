@@ -289,6 +289,21 @@ int rtx_fir_reflect(const void* in, int in_is_f64, int64_t ld_in, int n_rows, in
                     void* stream);
 int rtx_cubic_resample(const double* Ysm, int64_t ld, int n_rows, int64_t n, double x0, double h,
                        const double* x_out, int64_t n_out, double* out, int64_t ld_out, void* stream);
+/* rtx_cubic_resample without its range check, which reads a flag back from the device and therefore synchronises the
+ * stream: for a stream of spectra resampled onto ONE output axis that the caller has checked on the host (the loop of
+ * Generate_LWIR_TUD.py:117-150 calls reduceResolution, radiative_transfer.py:1327-1350, once per atmosphere). Fully
+ * asynchronous; an abscissa outside the supported range gives NaN. */
+/* The end regions of the same spline (within a window length of either end of the axis the reference's knots are not
+ * uniform -- it smooths the axis too, radiative_transfer.py:1331-1334, and smooth()'s reflection padding bends them -- and
+ * the not-a-knot end condition acts): the not-a-knot spline on the m local samples Ysm[r][i_first .. i_first+m) with the TRUE
+ * knots `knots[m]` (device, fp64; the smoothed axis there), natural at the cut; valid for x_out at least 24 knots inside
+ * the cut (2e-14). high_end = 0: local sample 0 is the first sample of the axis; 1: local sample m-1 is the last one.
+ * m <= 768. out: [n_rows][ld_out]. */
+int rtx_cubic_end(const double* Ysm, int64_t ld, int n_rows, int64_t i_first, int m, int high_end,
+                  const double* knots, const double* x_out, int64_t n_out, double* out, int64_t ld_out,
+                  void* stream);
+int rtx_cubic_resample_unchecked(const double* Ysm, int64_t ld, int n_rows, int64_t n, double x0, double h,
+                                 const double* x_out, int64_t n_out, double* out, int64_t ld_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Single-process collectives over the GPUs of one node. The reference has no multi-GPU code; its scripts are plain

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "rtx_pixel_cube": (_i32, [_i32, _i32, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rtx_fir_reflect": (_i32, [_vp, _i32, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
     "rtx_cubic_resample": (_i32, [_vp, _i64, _i32, _i64, _dbl, _dbl, _vp, _i64, _vp, _i64, _vp]),
+    "rtx_cubic_end": (_i32, [_vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "rtx_cubic_resample_unchecked": (_i32, [_vp, _i64, _i32, _i64, _dbl, _dbl, _vp, _i64, _vp, _i64, _vp]),
     "rtx_brightness_temperature": (_i32, [_vp, _i64, _vp, _i64, _i32, _dbl, _vp, _vp]),
     "rtx_bt2l": (_i32, [_vp, _i64, _vp, _i64, _i32, _dbl, _vp, _vp]),
     "rtx_comm_init_all": (_i32, [_i32, _vp, _i32, C.POINTER(_vp)]),

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void cubic_resample_kernel(const double* __res
   const double t = (x_out[q] - x0) * inv_h;
   long long i = (long long)floor(t);
   if (!(i - 1 - SPL_EDGE >= 0 && i + 2 + SPL_EDGE <= n - 1)) {  // also catches NaN
-    *bad = 1;
+    if (bad) *bad = 1;
+    else out[(size_t)blockIdx.y * (size_t)ld_out + (size_t)q] = __builtin_nan("");  // unchecked form: the point is marked, not reported
     return;
   }
   const double f = t - (double)i;
@@ -165,6 +166,23 @@ __global__ __launch_bounds__(256) void cubic_resample_kernel(const double* __res
   out[(size_t)row * (size_t)ld_out + (size_t)q] = (b0 * c0 + b1 * c1 + b2 * c2 + b3 * c3) * (1.0 / 6.0);
 }
 
+// The same without the device-to-host read-back of the range flag (which synchronises the stream): for callers that have
+// checked on the host that every x_out lies inside the supported range -- a stream of spectra resampled onto one output
+// axis (rt.compute_TUD_batch(reduce=...)). An abscissa outside the range gives NaN instead of an error.
+extern "C" int rtx_cubic_resample_unchecked(const double* Ysm, int64_t ld, int n_rows, int64_t n, double x0, double h,
+                                            const double* x_out, int64_t n_out, double* out, int64_t ld_out, void* stream) {
+  if (!Ysm || !x_out || !out) RTX_FAIL("a required pointer is NULL");
+  if (n_rows < 1 || n_rows > 65535) RTX_FAIL("n_rows=%d", n_rows);
+  if (n < 2 * SPL_EDGE + 8) RTX_FAIL("n=%lld: the spline needs at least %d samples", (long long)n, 2 * SPL_EDGE + 8);
+  if (!(h > 0.0)) RTX_FAIL("h=%g", h);
+  if (ld < n || ld_out < n_out) RTX_FAIL("leading dimension smaller than the row");
+  if (n_out == 0) return 0;
+  hipLaunchKernelGGL(cubic_resample_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, Ysm,
+                     (long long)ld, (long long)n, x0, 1.0 / h, x_out, (long long)n_out, out, (long long)ld_out, (int*)nullptr);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int rtx_cubic_resample(const double* Ysm, int64_t ld, int n_rows, int64_t n, double x0, double h, const double* x_out,
                                   int64_t n_out, double* out, int64_t ld_out, void* stream) {
   if (!Ysm || !x_out || !out) RTX_FAIL("a required pointer is NULL");
@@ -185,5 +203,90 @@ extern "C" int rtx_cubic_resample(const double* Ysm, int64_t ld, int n_rows, int
   RTX_HIP(hipStreamSynchronize(st));
   RTX_HIP(hipFreeAsync(d_bad, st));
   if (bad) RTX_FAIL("an output abscissa lies within %d samples of an end of the input axis (or is NaN)", SPL_EDGE + 2);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// End regions of reduceResolution's spline (radiative_transfer.py:1327-1350: scipy's interp1d(kind='cubic') = the
+// not-a-knot cubic spline through ALL smoothed samples). Away from the ends that spline is the cardinal spline on uniform
+// knots (rtx_cubic_resample); within a window length of an end it is not: the reference smooths the AXIS as well, and the
+// reflection padding of smooth() bends the first and last ceil(window/2) knots off the uniform grid, and the not-a-knot
+// end condition acts there. Both fade as 0.268^k with the distance k in knots, so the spline on the first (last) m knots,
+// with the true not-a-knot condition at the end of the axis and a natural condition at the cut -- 24 or more knots beyond
+// the last output -- is the reference's spline there to 0.268^24 = 2e-14. One workgroup per row: the local tridiagonal
+// system (second-derivative form on the true, non-uniform knots) is solved by one thread in LDS, then every thread
+// evaluates outputs. `high_end`: the window is the LAST m samples; it is mirrored on load so that the true end is index 0.
+#define SPL_END_MAX 768
+__global__ __launch_bounds__(256) void cubic_end_kernel(const double* __restrict__ y, long long ld, long long i_first, int m, int high_end,
+                                                        const double* __restrict__ knots, const double* __restrict__ x_out, long long n_out,
+                                                        double* __restrict__ out, long long ld_out) {
+  __shared__ double s_x[SPL_END_MAX], s_y[SPL_END_MAX], s_m[SPL_END_MAX], s_c[SPL_END_MAX], s_d[SPL_END_MAX];
+  const int row = blockIdx.x;
+  const double* __restrict__ src = y + (size_t)row * (size_t)ld + (size_t)i_first;
+  for (int j = threadIdx.x; j < m; j += blockDim.x) {
+    const int jj = high_end ? m - 1 - j : j;
+    s_x[j] = high_end ? -knots[jj] : knots[jj];
+    s_y[j] = src[jj];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // unknowns M_1 .. M_{m-2}; M_0 from the not-a-knot condition, M_{m-1} = 0 (natural, at the cut)
+    const double h0 = s_x[1] - s_x[0], h1 = s_x[2] - s_x[1];
+    double dprev = (s_y[1] - s_y[0]) / h0;
+    // forward sweep (Thomas): row i: a_i M_{i-1} + b_i M_i + c_i M_{i+1} = r_i
+    double cp = 0.0, dp = 0.0;  // modified coefficients of the previous row
+    for (int i = 1; i <= m - 2; ++i) {
+      const double hl = s_x[i] - s_x[i - 1], hr = s_x[i + 1] - s_x[i];
+      const double dcur = (s_y[i + 1] - s_y[i]) / hr;
+      double a = hl, b = 2.0 * (hl + hr), c = hr;
+      const double r = 6.0 * (dcur - dprev);
+      if (i == 1) {  // M_0 = (1 + h0/h1) M_1 - (h0/h1) M_2 folded in
+        b += h0 * (1.0 + h0 / h1);
+        c -= h0 * h0 / h1;
+        a = 0.0;
+      }
+      if (i == m - 2) c = 0.0;  // M_{m-1} = 0
+      const double den = b - a * cp;
+      cp = c / den;
+      dp = (r - a * dp) / den;
+      s_c[i] = cp;
+      s_d[i] = dp;
+      dprev = dcur;
+    }
+    s_m[m - 1] = 0.0;
+    double mn = 0.0;
+    for (int i = m - 2; i >= 1; --i) {
+      mn = s_d[i] - s_c[i] * mn;
+      s_m[i] = mn;
+    }
+    s_m[0] = (1.0 + h0 / h1) * s_m[1] - (h0 / h1) * s_m[2];
+  }
+  __syncthreads();
+  for (long long q = threadIdx.x; q < n_out; q += blockDim.x) {
+    const double x = high_end ? -x_out[q] : x_out[q];
+    // interval [x_i, x_{i+1}] holding x (clamped to the local knots: the host has checked the range)
+    int lo = 0, hi = m - 1;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_x[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double h = s_x[lo + 1] - s_x[lo], A = s_x[lo + 1] - x, B = x - s_x[lo];
+    const double v = (s_m[lo] * A * A * A + s_m[lo + 1] * B * B * B) / (6.0 * h) + (s_y[lo] / h - s_m[lo] * h / 6.0) * A +
+                     (s_y[lo + 1] / h - s_m[lo + 1] * h / 6.0) * B;
+    out[(size_t)row * (size_t)ld_out + (size_t)q] = v;
+  }
+}
+
+extern "C" int rtx_cubic_end(const double* Ysm, int64_t ld, int n_rows, int64_t i_first, int m, int high_end, const double* knots,
+                             const double* x_out, int64_t n_out, double* out, int64_t ld_out, void* stream) {
+  if (!Ysm || !knots || !x_out || !out) RTX_FAIL("a required pointer is NULL");
+  if (n_rows < 1 || n_rows > 65535) RTX_FAIL("n_rows=%d", n_rows);
+  if (m < 4 || m > SPL_END_MAX) RTX_FAIL("m=%d local knots outside [4,%d]", m, SPL_END_MAX);
+  if (i_first < 0 || i_first + m > ld) RTX_FAIL("local window [%lld, +%d) outside the row", (long long)i_first, m);
+  if (ld_out < n_out) RTX_FAIL("leading dimension smaller than the row");
+  if (n_out == 0) return 0;
+  hipLaunchKernelGGL(cubic_end_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, Ysm, (long long)ld, (long long)i_first, m,
+                     high_end, knots, x_out, (long long)n_out, out, (long long)ld_out);
+  RTX_LAUNCH_CHECK();
   return 0;
 }

@@ -659,44 +659,110 @@ def fir_reflect(Y, taps, centre):
     return out
 
 
-def cubic_resample(Ysm, x0, h, x_out):
-    """Cubic spline through every sample of the uniform axis x0 + i*h, at x_out (device fp64): [rows][n_out] fp64."""
+def cubic_resample(Ysm, x0, h, x_out, checked=True):
+    """Cubic spline through every sample of the uniform axis x0 + i*h, at x_out (device fp64): [rows][n_out] fp64.
+    checked=False: the caller has verified the range of x_out on the host; no device read-back, no synchronisation."""
     lib = _lib.load()
     assert Ysm.is_cuda and Ysm.dtype == torch.float64 and Ysm.dim() == 2 and Ysm.stride(1) == 1
     assert x_out.is_cuda and x_out.dtype == torch.float64 and x_out.dim() == 1 and x_out.is_contiguous()
     rows, n = Ysm.shape
     out = torch.empty((rows, x_out.numel()), dtype=torch.float64, device=Ysm.device)
-    _lib.check(lib.rtx_cubic_resample(_ptr(Ysm), Ysm.stride(0) if rows > 1 else n, rows, n, float(x0), float(h), _ptr(x_out), x_out.numel(),
-                                      _ptr(out), out.stride(0), _stream_ptr()))
+    fn = lib.rtx_cubic_resample if checked else lib.rtx_cubic_resample_unchecked
+    _lib.check(fn(_ptr(Ysm), Ysm.stride(0) if rows > 1 else n, rows, n, float(x0), float(h), _ptr(x_out), x_out.numel(),
+                  _ptr(out), out.stride(0), _stream_ptr()))
     return out
 
 
-def reduce_resolution(Y, x0, h, n, dX, N=4, window="hanning", x_out=None):
-    """Device-resident reduceResolution: Y [rows][n] (float32 as rtx_tud writes it, or float64) on the uniform axis
-    x0 + i*h -> (x_out host fp64, Y_out [rows][n_out] fp64 device). See radiative_transfer.reduceResolution."""
+SPL_END_GUARD = 24   # knots between the last output of an end region and the cut of its local spline (0.268^24 = 2e-14)
+SPL_END_MAX = 768    # local knots rtx_cubic_end takes
+
+
+def _smoothed_axis_ends(x0, h, n, taps, c, m):
+    """The first and last m values of the reference's smoothed axis X_ = sm(X) (radiative_transfer.py:1331-1334): the
+    symmetrised window applied to X = x0 + i*h with smooth()'s reflection padding. Host arithmetic on the axis only."""
+    k = np.arange(taps.size)
+    i = np.arange(m)
+    j = i[:, None] + k[None, :] - c
+    j = np.where(j < 0, -j, j)
+    lo = (taps[None, :] * (x0 + h * j)).sum(axis=1)
+    j = (n - m + i)[:, None] + k[None, :] - c
+    j = np.where(j >= n, 2 * (n - 1) - j, j)
+    hi = (taps[None, :] * (x0 + h * j)).sum(axis=1)
+    return lo, hi
+
+
+def _reduce_plan(x0, h, n, dX, N, window, x_out, device):
+    """Everything of reduceResolution that does not depend on the spectra: output axis, window taps, the split of the
+    outputs into a low-end region, the interior and a high-end region, and the true knots of the two end regions."""
     sm_factor = int(np.round(dX / h))
     if sm_factor < 3:
         raise ValueError(f"reduceResolution: dX/dX_in rounds to {sm_factor}; the window needs at least 3 samples")
     if window not in _WINDOWS:
         raise ValueError(f"window must be one of {_WINDOWS}")
+    taps, c = window_taps(sm_factor, window, symmetric=True)
     if x_out is None:
+        # the reference's default axis runs from X_[smFactor] to X_[-smFactor-1] (:1336-1338); a window length inside, the
+        # smoothed axis is the axis itself
         xa, xb = x0 + sm_factor * h, x0 + (n - sm_factor - 1) * h
         v = N * (xb - xa) / dX
-        n_pts = int(np.ceil(v - 1e-9 * max(1.0, abs(v)))) + 1  # see the shim's docstring: rounding-proof ceil
-        x_out = np.linspace(xa, xb, n_pts)
+        x_out = np.linspace(xa, xb, int(np.ceil(v - 1e-9 * max(1.0, abs(v)))) + 1)  # see the shim's docstring: rounding-proof ceil
     x_out = np.ascontiguousarray(x_out, dtype=np.float64)
-    # The reflection padding of smooth() distorts the first and last ceil(window/2) smoothed samples -- of Y and of the
-    # knot axis X_ itself, which is then no longer uniform there. The reference's spline feels those knots with weight
-    # 0.268^distance; the uniform-knot evaluation here is only offered where that is below 1e-11.
-    margin = (sm_factor + 1) // 2 + 20
-    if x_out.size and (x_out.min() < x0 + margin * h or x_out.max() > x0 + (n - 1 - margin) * h):
-        raise NotImplementedError(
-            f"reduceResolution: output points within {margin} samples of an end of the input axis are not supported "
-            f"(window {sm_factor}: the default X_out needs a window of at least 40 samples)")
-    taps, c = window_taps(sm_factor, window, symmetric=True)
+    # The interior evaluation (uniform knots, cardinal spline) is offered where the reflection padding of smooth() and the
+    # not-a-knot end condition have faded below 1e-11: `margin` samples inside. Outputs nearer an end go through the local
+    # not-a-knot spline on the true knots (rtx_cubic_end).
+    margin = max((sm_factor + 1) // 2 + 20, 27)  # (27: what rtx_cubic_resample itself asks of its abscissae)
+    x_lo, x_hi = x0 + margin * h, x0 + (n - 1 - margin) * h
+    n_lo = n_hi = 0
+    ends = None
+    if x_out.size and (x_out.min() < x_lo or x_out.max() > x_hi):
+        if np.any(np.diff(x_out) < 0):
+            raise NotImplementedError("reduceResolution: X_out must be ascending when it reaches into the end regions of the axis")
+        n_lo = int(np.searchsorted(x_out, x_lo, side="left"))
+        n_hi = int(x_out.size - np.searchsorted(x_out, x_hi, side="right"))
+        if n_lo + n_hi > x_out.size:  # a short axis: everything is an end region; the low end takes the lower half
+            n_lo = int(np.searchsorted(x_out, x0 + 0.5 * (n - 1) * h, side="left"))
+            n_hi = x_out.size - n_lo
+        m = min(n, margin + SPL_END_GUARD + 2 + (sm_factor + 1) // 2)
+        if m > SPL_END_MAX:
+            raise NotImplementedError(
+                f"reduceResolution: output points within {margin} samples of an end of the input axis need a local spline of {m} "
+                f"knots (window {sm_factor}); supported up to {SPL_END_MAX}")
+        k_lo, k_hi = _smoothed_axis_ends(x0, h, n, taps, c, m)
+        if (n_lo and x_out[0] < k_lo[0]) or (n_hi and x_out[-1] > k_hi[-1]):
+            raise NotImplementedError("reduceResolution: X_out outside the smoothed axis (extrapolation is not supported)")
+        if m < n and ((n_lo and x_out[n_lo - 1] > k_lo[m - 1 - SPL_END_GUARD]) or (n_hi and x_out[x_out.size - n_hi] < k_hi[SPL_END_GUARD])):
+            raise NotImplementedError("reduceResolution: the axis is too short for its end regions to be treated separately")
+        ends = (m, torch.as_tensor(k_lo, device=device), torch.as_tensor(k_hi, device=device))
+    return x_out, torch.as_tensor(x_out, device=device), taps, c, n_lo, n_hi, ends
+
+
+def _reduce_apply(Y, x0, h, n, plan, checked):
+    x_out, x_dev, taps, c, n_lo, n_hi, ends = plan
     Ysm = fir_reflect(Y, taps, c)
-    out = cubic_resample(Ysm, x0, h, torch.as_tensor(x_out, device=Y.device))
+    n_out = x_out.size
+    n_mid = n_out - n_lo - n_hi
+    if not (n_lo or n_hi):
+        return x_out, cubic_resample(Ysm, x0, h, x_dev, checked=checked)
+    lib = _lib.load()
+    rows = Ysm.shape[0]
+    out = torch.empty((rows, n_out), dtype=torch.float64, device=Y.device)
+    ld = Ysm.stride(0) if rows > 1 else n
+    m, k_lo, k_hi = ends
+    if n_lo:
+        _lib.check(lib.rtx_cubic_end(_ptr(Ysm), ld, rows, 0, m, 0, _ptr(k_lo), C.c_void_p(x_dev.data_ptr()), n_lo,
+                                     C.c_void_p(out.data_ptr()), out.stride(0), _stream_ptr()))
+    if n_mid:
+        out[:, n_lo:n_lo + n_mid] = cubic_resample(Ysm, x0, h, x_dev[n_lo:n_lo + n_mid], checked=checked)
+    if n_hi:
+        _lib.check(lib.rtx_cubic_end(_ptr(Ysm), ld, rows, n - m, m, 1, _ptr(k_hi), C.c_void_p(x_dev.data_ptr() + 8 * (n_out - n_hi)), n_hi,
+                                     C.c_void_p(out.data_ptr() + 8 * (n_out - n_hi)), out.stride(0), _stream_ptr()))
     return x_out, out
+
+
+def reduce_resolution(Y, x0, h, n, dX, N=4, window="hanning", x_out=None):
+    """Device-resident reduceResolution: Y [rows][n] (float32 as rtx_tud writes it, or float64) on the uniform axis
+    x0 + i*h -> (x_out host fp64, Y_out [rows][n_out] fp64 device). See radiative_transfer.reduceResolution."""
+    return _reduce_apply(Y, x0, h, n, _reduce_plan(x0, h, n, dX, N, window, x_out, Y.device), checked=True)
 
 
 _REDUCE_PLANS = {}
@@ -705,27 +771,13 @@ _REDUCE_PLANS = {}
 def reduce_resolution_cached(Y, x0, h, n, dX, N=4, window="hanning"):
     """reduce_resolution on its default output axis, for a stream of spectra on one grid (compute_TUD_batch: every
     atmosphere of a batch is reduced the same way): the output axis (host and device copies), the symmetrised window taps
-    (a Python loop over the window) and the range checks are made once per (axis, dX, N, window, device) instead of per
-    spectrum -- together they cost more host time than the device needs for the whole atmosphere."""
+    (a Python loop over the window), the end-region knots and the range checks are made once per (axis, dX, N, window,
+    device) instead of per spectrum -- together they cost more host time than the device needs for the whole atmosphere --
+    and the resampling runs without its device read-back."""
     key = (float(x0), float(h), int(n), float(dX), int(N), window, Y.device.index)
     plan = _REDUCE_PLANS.get(key)
     if plan is None:
-        sm_factor = int(np.round(dX / h))
-        if sm_factor < 3:
-            raise ValueError(f"reduceResolution: dX/dX_in rounds to {sm_factor}; the window needs at least 3 samples")
-        if window not in _WINDOWS:
-            raise ValueError(f"window must be one of {_WINDOWS}")
-        xa, xb = x0 + sm_factor * h, x0 + (n - sm_factor - 1) * h
-        v = N * (xb - xa) / dX
-        x_out = np.linspace(xa, xb, int(np.ceil(v - 1e-9 * max(1.0, abs(v)))) + 1)
-        margin = (sm_factor + 1) // 2 + 20
-        if x_out.size and (x_out.min() < x0 + margin * h or x_out.max() > x0 + (n - 1 - margin) * h):
-            raise NotImplementedError(
-                f"reduceResolution: output points within {margin} samples of an end of the input axis are not supported "
-                f"(window {sm_factor}: the default X_out needs a window of at least 40 samples)")
-        taps, c = window_taps(sm_factor, window, symmetric=True)
         if len(_REDUCE_PLANS) > 8:
             _REDUCE_PLANS.clear()
-        plan = _REDUCE_PLANS[key] = (x_out, torch.as_tensor(x_out, device=Y.device), taps, c)
-    x_out, x_dev, taps, c = plan
-    return x_out, cubic_resample(fir_reflect(Y, taps, c), x0, h, x_dev)
+        plan = _REDUCE_PLANS[key] = _reduce_plan(x0, h, n, dX, N, window, None, Y.device)
+    return _reduce_apply(Y, x0, h, n, plan, checked=False)

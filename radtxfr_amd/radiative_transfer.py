@@ -634,9 +634,10 @@ def reduceResolution(X, Y, dX, N=4, window="hanning", X_out=None):
     scipy's cubic interp1d through all smoothed samples. Here: one fp64 FIR kernel and one cardinal-spline kernel.
     Conscious divergences: (1) nPts = ceil(N*span/dX)+1 is evaluated with a 1e-9 guard, because N*span/dX is normally
     an exact integer and the reference's value flips between two counts with the rounding of its convolution;
-    (2) X_out must stay ceil(window/2) + 20 samples inside the input axis (the default X_out does for windows of
-    >= 40 samples; the reference's main caller uses 500), else NotImplementedError: the not-a-knot end conditions and
-    the extrapolation of interp1d are not reproduced; (3) np.int (:1329,1336) is int."""
+    (2) np.int (:1329,1336) is int; (3) X_out must be ascending when it reaches within ceil(window/2) + 20 samples of an
+    end of the axis, and must not leave the smoothed axis (interp1d's extrapolation is not reproduced). Output points near
+    the ends -- where the reference's knots are the SMOOTHED, no longer uniform axis and its not-a-knot end condition acts --
+    are evaluated by a local not-a-knot spline on those knots (rtx_cubic_end), so short windows work with the default X_out."""
     Xh, h = _uniform_axis(X, "reduceResolution")
     engine.require_gpu()
     Yt = Y if _is_torch(Y) else torch.as_tensor(np.asarray(Y, dtype=np.float64))

@@ -1187,8 +1187,10 @@ def test_reduce_resolution_random_configurations_vs_oracle(rt):
         assert Yo.shape == Yo_ref.shape and rel_err(Yo, Yo_ref) < 1e-9, tag
         Xq = np.sort(rng.uniform(X[sm // 2 + 24], X[-sm // 2 - 26], 57))
         assert rel_err(rt.reduceResolution(X, Y, dX, N=N, window=win, X_out=Xq), ref.reduceResolution(X, Y, dX, N=N, window=win, X_out=Xq)) < 1e-9, tag
-    with pytest.raises(NotImplementedError):  # a short window: the distorted end samples are too close to the first output point
-        rt.reduceResolution(X, Y, 12 * h)
+    # a short window: the first output points lie among the distorted end knots -- evaluated by the local end-region spline
+    xs_r, ys_r = ref.reduceResolution(X, Y, 12 * h)
+    ys = rt.reduceResolution(X, Y, 12 * h, X_out=xs_r)  # (on the reference's axis: its point count can flip by one)
+    assert ys.shape == ys_r.shape and rel_err(ys, ys_r) < 1e-9
 
 
 def test_hapi_shim_option_combinations_vs_oracle(hapi):
@@ -1431,6 +1433,41 @@ def test_compute_tud_batch_devices_and_host_paths(rt):
     Xw *= 2.0
     assert np.array_equal(rt.compute_TUD(lo, hi, **dict(common, **atms[0]))[0], Xc)
     lines.close()
+
+
+def test_reduce_resolution_end_regions_vs_oracle(rt):
+    """reduceResolution with SHORT windows and output points close to the ends of the axis (radiative_transfer.py:1327-1350):
+    there the reference's spline runs on the smoothed -- no longer uniform -- axis and its not-a-knot end condition acts; the
+    engine evaluates those points with a local not-a-knot spline on the true knots (rtx_cubic_end), the rest with the
+    cardinal spline. Against the oracle (scipy's interp1d through all smoothed samples): default X_out for windows of 5 to
+    60 samples, explicit X_out reaching to the first and last smoothed knot, 2-D Y, float32 device rows."""
+    import torch
+    from radtxfr_amd import engine
+    rng = np.random.default_rng(21)
+    n = 6000
+    X = np.linspace(700.0, 760.0 - 0.01, n)  # step 0.01
+    Y = np.exp(-0.5 * ((X[:, None] - np.array([700.3, 730.0, 759.6])) / np.array([0.4, 2.5, 0.3])) ** 2) + 0.05 * rng.standard_normal((n, 3)) * 0.01
+    for dX in (0.05, 0.1, 0.21, 0.37, 0.6):
+        xo_r, yo_r = ref.reduceResolution(X, Y, dX)
+        xo, yo = rt.reduceResolution(X, Y, dX)
+        assert xo.shape == xo_r.shape and np.allclose(xo, xo_r, rtol=0, atol=1e-9), dX
+        assert rel_err(yo, yo_r) <= 1e-9, (dX, rel_err(yo, yo_r))
+        y1 = rt.reduceResolution(X, Y[:, 1], dX, X_out=xo)
+        assert rel_err(y1, yo_r[:, 1]) <= 1e-9
+    # explicit abscissae from the very first to the very last smoothed knot
+    dX = 0.1
+    Xs = ref.smooth_sym(X, 10)
+    xq = np.concatenate([np.linspace(Xs[0], Xs[40], 57), np.linspace(X[100], X[-100], 301), np.linspace(Xs[-41], Xs[-1], 63)])
+    want = ref.reduceResolution(X, Y, dX, X_out=xq)
+    got = rt.reduceResolution(X, Y, dX, X_out=xq)
+    assert rel_err(got, want) <= 1e-9, rel_err(got, want)
+    with pytest.raises(NotImplementedError):
+        rt.reduceResolution(X, Y, dX, X_out=np.array([X[0] - 1.0, X[50]]))  # extrapolation
+    # device-resident float32 rows through the engine (what compute_TUD_batch(reduce=...) does), short window
+    rows = torch.as_tensor(Y.T.astype(np.float32), device="cuda").contiguous()
+    xo_e, out = engine.reduce_resolution_cached(rows, float(X[0]), float(X[1] - X[0]), n, 0.1)
+    xo_r, yo_r = ref.reduceResolution(X, Y.astype(np.float32).astype(np.float64), 0.1)
+    assert np.allclose(xo_e, xo_r, rtol=0, atol=1e-9) and rel_err(out.cpu().numpy().T, yo_r) <= 1e-9
 
 
 def test_compute_tud_chunked_equals_unchunked(rt):
