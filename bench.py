@@ -233,6 +233,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the interpreter's cyclic garbage collector is parked for the timed loop: a full collection takes 40-70 ms with torch's
+    # object graph loaded (profiles/r3_time_dropin.txt) -- a hundred steps of an eighth-of-the-grid shard -- and says nothing about
+    # the path; reference counting still frees everything the loop allocates
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     sync()
@@ -241,6 +247,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
