@@ -242,12 +242,14 @@ int rtx_band_mix(const float* N, const float* C, const float* M, const int32_t* 
  * (LWIR_HSI_Generator.py:151-167: em = mixFrac . emis[ix_em], T = Ts + dT*N(0,1),
  * L = tau*(em*B(T) + (1-em)*Ld) + La), evaluated at monochromatic resolution and passed through
  * the ILS. B(nu, T_p) is interpolated over each band's support through Q Chebyshev nodes
- * (Q = 5: < 2e-10 relative), which makes the monochromatic pass pixel-independent:
+ * (Q = 4: < 7e-9 relative over the MAKO bands, 230-350 K), which makes the monochromatic pass pixel-independent:
  *   rtx_band_basis_moments -> N[nB], C[nB], MLd[nB][nk], MB[Q][nB][nk], jrange[nB][2]
  *       basis_coef_h[Q][Q]: monomial coefficients of the Lagrange basis l_q(s), s = (nu-c_b)/(node_span*sigma_b)
- *   rtx_band_mix (N = C = NULL) contracts MLd / each MB[q] with the endmember knot spectra E[nk][nEnd]
- *       -> ALd[nB][nEnd], AB[Q][nB][nEnd]
+ *       (MLd_out may be row Q of one [Q+1][nB][nk] array whose rows 0..Q-1 are MB_out)
+ *   rtx_band_mix_stacked contracts the n_stack = Q+1 moment arrays M[n_stack][nB][nk] with the endmember knot
+ *       spectra E[nk][nEnd] in one launch -> tab[nEnd][n_stack][nB] (bands innermost: what rtx_pixel_cube reads)
  *   rtx_pixel_cube -> cube[nB][nPix] float32 (bands first):
+ *       tab[nEnd][Q+1][nB]: rows 0..Q-1 the Planck-node tables, row Q the downwelling table;
  *       kidx[nPix][nMix] int32 endmember indices, frac[nPix][nMix] float32, Tpix[nPix] fp64 (device);
  *       s_node_h[Q] the Chebyshev nodes in s. */
 int rtx_band_basis_moments(int kind, const rtx_grid* grid, const float* tau, const float* La,
@@ -256,10 +258,12 @@ int rtx_band_basis_moments(int kind, const rtx_grid* grid, const float* tau, con
                            const float* basis_coef_h, double node_span, float* N_out,
                            float* C_out, float* MLd_out, float* MB_out, int32_t* jrange_out,
                            void* stream);
+int rtx_band_mix_stacked(const float* M, const int32_t* jrange, int nB, int n_stack, int64_t nk,
+                         const float* E, int64_t nE, float* tab, void* stream);
 int rtx_pixel_cube(int nB, int Q, const double* centre, const double* sigma, double node_span,
-                   const float* s_node_h, const float* N, const float* C, const float* ALd,
-                   const float* AB, int nEnd, int64_t nPix, int nMix, const int32_t* kidx,
-                   const float* frac, const double* Tpix, float* cube, void* stream);
+                   const float* s_node_h, const float* N, const float* C, const float* tab,
+                   int nEnd, int64_t nPix, int nMix, const int32_t* kidx, const float* frac,
+                   const double* Tpix, float* cube, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Speed-dependent Voigt line-sum. Replaces the per-line PROFILE_SDVOIGT + scatter-add of

@@ -53,7 +53,8 @@ PROTOTYPES = {
     "rtx_band_mix": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp]),
     "rtx_band_basis_moments": (_i32, [_i32, _gp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _dbl,
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
-    "rtx_pixel_cube": (_i32, [_i32, _i32, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rtx_band_mix_stacked": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _i64, _vp, _vp]),
+    "rtx_pixel_cube": (_i32, [_i32, _i32, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rtx_fir_reflect": (_i32, [_vp, _i32, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
     "rtx_cubic_resample": (_i32, [_vp, _i64, _i32, _i64, _dbl, _dbl, _vp, _i64, _vp, _i64, _vp]),
     "rtx_cubic_end": (_i32, [_vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),

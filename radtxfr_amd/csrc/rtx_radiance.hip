@@ -896,12 +896,12 @@ extern "C" int rtx_band_mix(const float* N, const float* C, const float* M, cons
 // B(nu, T_p) is the only pixel-dependent factor inside the monochromatic sum. Over the support of one band
 // (a few cm^-1 to ~25 cm^-1) it is a very smooth function of nu, so it is replaced by its degree-(Q-1)
 // interpolant through Q Chebyshev nodes of the band:  B(nu,T) = sum_q l_q(s) B(nu_bq, T),  s = (nu-c_b)/R_b.
-// For Q = 5 the interpolation error is < 2e-10 relative (|d ln B/d nu| < 5e-3 per cm^-1), three orders below
-// fp32 rounding. Then
+// Worst pointwise interpolation error over the MAKO bands, 230-350 K (NumPy): Q = 4 (sensor.hsi_cube's default)
+// 4e-10 relative at resFactor 2, 7e-9 without; Q = 5: 2e-12 / 6e-11; Q = 3: 4e-7 / 3e-6 -- fp32 rounding is 6e-8. Then
 //   L_b,p = [ C_b + sum_m f_pm ( sum_q B(nu_bq,T_p) AB[q][b][k_m] - ALd[b][k_m] ) ] / N_b
 // with pixel-independent tables from ONE monochromatic pass: MB[q][b][j] = sum_i w tau l_q hat_j,
 // MLd[b][j] = sum_i w tau Ld hat_j (rtx_band_basis_moments), contracted with the endmember knot spectra
-// (rtx_band_mix), and a per-(band, pixel) kernel with Q Planck evaluations (rtx_pixel_cube).
+// (rtx_band_mix_stacked), and a per-(band, pixel) kernel with Q Planck evaluations (rtx_pixel_cube).
 #define CUBE_QMAX 6
 struct BasisArgs {
   int kind, Q;
@@ -922,84 +922,247 @@ struct BasisArgs {
   int2* jrange;
 };
 
-__global__ __launch_bounds__(256) void band_basis_moments_kernel(BasisArgs a) {
-  __shared__ float s_red[4];
-  const int b = blockIdx.x, Q = a.Q;
+// One workgroup per band; its 16 waves take (knot interval, quarter) tasks. Quarter r of an interval is the points
+// first + 64 r + lane + 256 it: counted from the interval's first point, so a band's bits do not depend on where the grid
+// shard starts. A wave reduces its sums over the lanes (DPP adds, fixed order) and parks them in LDS; after every round of
+// BBM_SEGS intervals one thread per (row, knot) adds the quarters (fixed tree) of the intervals that meet at the knot, in
+// interval order, and writes the knot.
+// A band is ONE compute unit's work, and the widest MAKO band (14 knot intervals x 1000 points) sets the kernel's time.
+// History for C5's 256 bands: 127 us (round 2: the whole workgroup walked the intervals one after the other, 28 barriers per
+// interval) -> 48 (a wave per interval) -> 52 (16 waves, quarters, knots counted in one pass instead of two binary searches,
+// loads issued ahead: no gain -- stamps inside the kernel: 7.6 us before the first task, 40 us in the tasks of the widest
+// band, i.e. ~200 instructions per point, 50 of them fp64, on one CU) -> the per-point quantities (x - c, the interpolation
+// weight, the node abscissa) are LINEAR in the point index: one fp64 evaluation per task, an FMA per point; basis polynomials
+// of degree Q - 1 (not CUBE_QMAX - 1) with their coefficients in vector registers; knot -> grid index once per round, not per
+// task; rows written once by the combine (zeros outside the band's knots stored at the end, off the critical path).
+#ifndef CUBE_ABLATE
+#define CUBE_ABLATE 0  // timing experiments only (tools/build_variant.sh)
+#endif
+#define BBM_WAVES 16
+#define BBM_SEGS 16
+#define BBM_PARTS 4
+#define BBM_UNROLL 4
+#define BBM_NVMAX (2 * CUBE_QMAX + 4)  // G0[0..Q-1], G1[0..Q-1], G0 and G1 of the Ld moment, N, C
+
+// grid_lower_bound without the search: the index from the grid's arithmetic, then stepped until it is the first with X >= v
+__device__ __forceinline__ long long grid_lower_bound_direct(const GridDev& g, long long n, double v) {
+  const double r = ceil((v - g.xmin) / g.step) - (double)g.offset;
+  long long i = r <= 0.0 ? 0 : (r >= (double)n ? n : (long long)r);  // NaN -> n
+  while (i > 0 && grid_x(g, g.offset + i - 1) >= v) --i;
+  while (i < n && grid_x(g, g.offset + i) < v) ++i;
+  return i;
+}
+
+// sum over the wave, valid in lane 63: shifts within the rows of 16 lanes, then the two row broadcasts (fixed order)
+__device__ __forceinline__ float wave_sum63(float v) {
+#define RTX_DPP_ADD(ctrl, rows) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, true))
+  RTX_DPP_ADD(0x111, 0xf);  // row_shr:1
+  RTX_DPP_ADD(0x112, 0xf);  // row_shr:2
+  RTX_DPP_ADD(0x114, 0xf);  // row_shr:4
+  RTX_DPP_ADD(0x118, 0xf);  // row_shr:8  -> lane 15 of a row: the row's sum
+  RTX_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  RTX_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef RTX_DPP_ADD
+  return v;
+}
+
+template <int KIND, int Q>
+__global__ __launch_bounds__(64 * BBM_WAVES) void band_basis_moments_kernel(BasisArgs a) {
+  constexpr int NV = 2 * Q + 4, IG0 = 0, IG1 = Q, IL0 = 2 * Q, IL1 = 2 * Q + 1, IN = 2 * Q + 2, IC = 2 * Q + 3;
+  __shared__ float s_seg[BBM_SEGS][BBM_PARTS][BBM_NVMAX];
+  __shared__ int s_j[BBM_SEGS][2];  // j0, j1 of the interval; j0 = -1: no points
+  __shared__ double s_xk[BBM_SEGS + 1];
+  __shared__ long long s_pk[BBM_SEGS + 1];
+  __shared__ int s_cnt[2];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if CUBE_ABLATE & 256
+  const unsigned long long T0 = wall_clock64();
+  unsigned long long T1 = 0, T2 = 0, T3 = 0;
+#endif
+  // this thread's first knot of the count below, asked for together with the band's centre and width: one trip to memory
+  const double xk_mine = (long long)threadIdx.x < a.nk ? a.Xk[threadIdx.x] : 1.0e300;
   const double c = a.centre[b], s = a.sigma[b];
-  const double R = a.kind == 0 ? s : 14.0 * s;
+  const double R = KIND == 0 ? s : 14.0 * s;
   const double inv_Rn = 1.0 / ((double)a.node_span * s);
-  long long lo = grid_lower_bound(a.g, a.nx, c - R);
+  long long lo = grid_lower_bound_direct(a.g, a.nx, c - R);
   while (lo < a.nx && !(grid_x(a.g, a.g.offset + lo) > c - R)) ++lo;
-  const long long hi = grid_lower_bound(a.g, a.nx, c + R);
-  float* MLd = a.MLd + (size_t)b * a.nk;
+  const long long hi = grid_lower_bound_direct(a.g, a.nx, c + R);
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  // knot intervals jj = -1 (left of the first knot) .. nk-1 (right of the last): np.interp holds the end values.
+  // first interval that can contain X[lo]: (#knots <= X[lo]) - 1; last one: (#knots <= X[hi-1]) - 1
+  if (lo < hi) {
+    const double x_first = grid_x(a.g, a.g.offset + lo), x_last = grid_x(a.g, a.g.offset + hi - 1);
+    int c1 = xk_mine <= x_first ? 1 : 0, c2 = xk_mine <= x_last ? 1 : 0;
+    for (long long j = threadIdx.x + blockDim.x; j < a.nk; j += blockDim.x) {
+      const double xk = a.Xk[j];
+      c1 += xk <= x_first ? 1 : 0;
+      c2 += xk <= x_last ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) { c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); }
+    if (lane == 0) { atomicAdd(&s_cnt[0], c1); atomicAdd(&s_cnt[1], c2); }
+  }
+  float cv[Q][Q];  // the basis coefficients in vector registers (an FMA with a scalar-register source issues at half rate)
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int d = 0; d < Q; ++d) asm volatile("v_mov_b32 %0, %1" : "=v"(cv[q][d]) : "s"(a.coef[q][d]));
+  const float step_f = (float)a.g.step, inv_s = (float)(1.0 / s), inv_Rn_f = (float)inv_Rn;
+  __syncthreads();
+  const long long jj_first = lo < hi ? s_cnt[0] - 1 : 0, jj_last = lo < hi ? max(s_cnt[0], s_cnt[1]) - 1 : -2;
+#if CUBE_ABLATE & 256
+  T1 = wall_clock64();
+#endif
+  float Nacc = 0.f, Cacc = 0.f;  // the last thread only
+  int jfirst = 0x7fffffff, jlast = -1;
+  long long w_lo = 0, w_hi = -1;  // knots written by the combine
+  for (long long base = jj_first; base <= jj_last; base += BBM_SEGS) {
+    if (threadIdx.x <= BBM_SEGS) {
+      const double xk = a.Xk[min(max(base + (long long)threadIdx.x, 0ll), a.nk - 1)];
+      s_xk[threadIdx.x] = xk;
+      s_pk[threadIdx.x] = grid_lower_bound_direct(a.g, a.nx, xk);
+    }
+    __syncthreads();
+    for (int task = wave; task < BBM_SEGS * BBM_PARTS && base + task / BBM_PARTS <= jj_last; task += BBM_WAVES) {
+      const int slot = task / BBM_PARTS, part = task % BBM_PARTS;
+      const long long jj = base + slot;
+      const long long j0 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj);
+      const long long j1 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj + 1);
+      const double x0 = s_xk[slot], dxk = s_xk[slot + 1] - x0;  // Xk[j0], Xk[j1] - Xk[j0]
+      const long long p_lo = jj == jj_first ? lo : s_pk[slot];
+      const long long p_hi = jj == jj_last ? hi : s_pk[slot + 1];
+      const double inv_dxk_d = dxk > 0.0 ? 1.0 / dxk : 0.0;
+      float v[NV];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = 0.f;
+      // x - c, f = (x - Xk[j0]) / dxk and the node abscissa as linear functions of the offset from the interval's first point
+      const double x_ref = grid_x(a.g, a.g.offset + p_lo);
+      const float d0 = (float)(x_ref - c), f00 = (float)((x_ref - x0) * inv_dxk_d), fstep = (float)(a.g.step * inv_dxk_d);
+      const bool linear = KIND == 0 && p_hi - p_lo < (1ll << 24);  // offsets exact in fp32
+      if (!(CUBE_ABLATE & 2))
+      for (long long ib = p_lo + part * 64; ib < p_hi; ib += 64 * BBM_PARTS * BBM_UNROLL) {
+        float tt[BBM_UNROLL], ll[BBM_UNROLL], aa[BBM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BBM_UNROLL; ++u) {  // all loads first: one trip to memory per BBM_UNROLL points
+          const long long i = ib + u * (64 * BBM_PARTS) + lane;
+          const long long ic = i < p_hi ? i : p_lo;
+          tt[u] = a.tau[ic]; ll[u] = a.Ld[ic]; aa[u] = a.La[ic];
+        }
+        const int rel0 = (int)(ib - p_lo) + lane;
+#pragma unroll
+        for (int u = 0; u < BBM_UNROLL; ++u) {
+          const long long i = ib + u * (64 * BBM_PARTS) + lane;
+          const bool ok = i < p_hi;
+          float w, f, sn;
+          if (linear) {
+            const float uf = (float)(rel0 + u * (64 * BBM_PARTS));
+            const float d = fmaf(uf, step_f, d0);
+            w = fmaxf(fmaf(-fabsf(d), inv_s, 1.0f), 0.f);  // tri(), :1236-1239
+            f = fmaf(uf, fstep, f00);
+            sn = d * inv_Rn_f;
+          } else {
+            const double x = grid_x(a.g, a.g.offset + i);
+            w = ils_weight(KIND, x, c, s);
+            f = (float)((x - x0) * inv_dxk_d);
+            sn = (float)((x - c) * inv_Rn);
+          }
+          w = ok ? w : 0.f;  // past the interval's end: the first point again, with weight 0
+          const float t = tt[u], ld = ll[u];
+          const float wt = w * t, f1 = 1.0f - f;
+          v[IN] += w;
+          v[IC] = fmaf(w, fmaf(t, ld, aa[u]), v[IC]);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            float l = cv[q][Q - 1];
+#pragma unroll
+            for (int d = Q - 2; d >= 0; --d) l = fmaf(l, sn, cv[q][d]);
+            const float gq = wt * l;
+            v[IG1 + q] = fmaf(gq, f, v[IG1 + q]);
+            v[IG0 + q] = fmaf(gq, f1, v[IG0 + q]);
+          }
+          const float gl = wt * ld;
+          v[IL1] = fmaf(gl, f, v[IL1]);
+          v[IL0] = fmaf(gl, f1, v[IL0]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const float r = wave_sum63(v[q]);
+        if (lane == 63) s_seg[slot][part][q] = r;
+      }
+      if (lane == 0 && part == 0) {
+        s_j[slot][0] = p_hi > p_lo ? (int)j0 : -1;
+        s_j[slot][1] = (int)j1;
+      }
+    }
+    __syncthreads();
+#if CUBE_ABLATE & 256
+    if (!T2) T2 = wall_clock64();
+#endif
+    const int n_slots = (int)min((long long)BBM_SEGS, jj_last - base + 1);
+    const long long jb = base < 0 ? 0 : base;
+    if (base == jj_first) w_lo = jb;
+    w_hi = min(a.nk - 1, jb + n_slots);
+    // knot j of this round collects, in interval order, the j0-sum of the intervals that start at it and the j1-sum of those
+    // that end at it (the order one thread walking the intervals would add them in); one thread per (row, knot)
+    if (CUBE_ABLATE & 4) {
+    } else if (threadIdx.x < (unsigned)((Q + 1) * (BBM_SEGS + 1))) {
+      const int qi = threadIdx.x / (BBM_SEGS + 1), jl = threadIdx.x % (BBM_SEGS + 1);
+      const int i0 = qi == Q ? IL0 : IG0 + qi, i1 = qi == Q ? IL1 : IG1 + qi;  // rows 0..Q-1: the basis moments, row Q: Ld
+      const long long j = jb + jl;
+      float acc = 0.f;
+      for (int sl = 0; sl < n_slots; ++sl) {
+        const int j0 = s_j[sl][0];
+        if (j0 < 0) continue;
+        if (j0 == j) acc += (s_seg[sl][0][i0] + s_seg[sl][1][i0]) + (s_seg[sl][2][i0] + s_seg[sl][3][i0]);
+        if (s_j[sl][1] == j) acc += (s_seg[sl][0][i1] + s_seg[sl][1][i1]) + (s_seg[sl][2][i1] + s_seg[sl][3][i1]);
+      }
+      if (jl <= n_slots && j <= w_hi) {
+        float* row = (qi == Q) ? a.MLd + (size_t)b * a.nk : a.MB + ((size_t)qi * a.nB + b) * a.nk;
+        if (base != jj_first && jl == 0) row[j] += acc; else row[j] = acc;  // the knot shared with the previous round
+      }
+    } else if (threadIdx.x == 64 * BBM_WAVES - 1) {
+      for (int sl = 0; sl < n_slots; ++sl) {
+        const int j0 = s_j[sl][0];
+        if (j0 < 0) continue;
+        Nacc += (s_seg[sl][0][IN] + s_seg[sl][1][IN]) + (s_seg[sl][2][IN] + s_seg[sl][3][IN]);
+        Cacc += (s_seg[sl][0][IC] + s_seg[sl][1][IC]) + (s_seg[sl][2][IC] + s_seg[sl][3][IC]);
+        jfirst = min(jfirst, j0);
+        jlast = max(jlast, s_j[sl][1]);
+      }
+    }
+    __syncthreads();
+  }
+  // zeros on the knots the band does not reach
   for (long long j = threadIdx.x; j < a.nk; j += blockDim.x) {
-    MLd[j] = 0.f;
+    if (j >= w_lo && j <= w_hi) continue;
+    a.MLd[(size_t)b * a.nk + j] = 0.f;
+#pragma unroll
     for (int q = 0; q < Q; ++q) a.MB[((size_t)q * a.nB + b) * a.nk + j] = 0.f;
   }
-  float Nsum = 0.f, Csum = 0.f;
-  int jfirst = 0x7fffffff, jlast = -1;
-  long long p_lo = lo, jj;
-  {
-    const double x_first = lo < a.nx ? grid_x(a.g, a.g.offset + lo) : 0.0;
-    long long l2 = 0, h2 = a.nk;
-    while (l2 < h2) { const long long mid = (l2 + h2) >> 1; if (a.Xk[mid] <= x_first) l2 = mid + 1; else h2 = mid; }
-    jj = l2 - 1;
-  }
-  while (p_lo < hi) {
-    const long long p_hi = (jj + 1 < a.nk) ? min(hi, grid_lower_bound(a.g, a.nx, a.Xk[jj + 1])) : hi;
-    const long long j0 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj);
-    const long long j1 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj + 1);
-    const double x0 = a.Xk[j0], dxk = a.Xk[j1] - a.Xk[j0];
-    float G0[CUBE_QMAX + 1], G1[CUBE_QMAX + 1];  // [0..Q-1]: basis moments, [Q]: the Ld moment
-#pragma unroll
-    for (int q = 0; q <= CUBE_QMAX; ++q) G0[q] = G1[q] = 0.f;
-    for (long long i = p_lo + threadIdx.x; i < p_hi; i += blockDim.x) {
-      const double x = grid_x(a.g, a.g.offset + i);
-      const float w = ils_weight(a.kind, x, c, s);
-      const float t = a.tau[i], ld = a.Ld[i];
-      const float f = dxk > 0.0 ? (float)((x - x0) / dxk) : 0.f;
-      const float sn = (float)((x - c) * inv_Rn);
-      const float wt = w * t;
-      Nsum += w;
-      Csum = fmaf(w, fmaf(t, ld, a.La[i]), Csum);
-#pragma unroll
-      for (int q = 0; q < CUBE_QMAX; ++q) {
-        if (q < Q) {
-          float l = a.coef[q][CUBE_QMAX - 1];
-#pragma unroll
-          for (int d = CUBE_QMAX - 2; d >= 0; --d) l = fmaf(l, sn, a.coef[q][d]);
-          const float gq = wt * l;
-          G1[q] = fmaf(gq, f, G1[q]);
-          G0[q] = fmaf(gq, 1.0f - f, G0[q]);
-        }
-      }
-      const float gl = wt * ld;
-      G1[CUBE_QMAX] = fmaf(gl, f, G1[CUBE_QMAX]);
-      G0[CUBE_QMAX] = fmaf(gl, 1.0f - f, G0[CUBE_QMAX]);
-    }
-    if (p_hi > p_lo) {
-#pragma unroll
-      for (int q = 0; q <= CUBE_QMAX; ++q) {
-        if (q < Q || q == CUBE_QMAX) {
-          const float g0 = block_sum(G0[q], s_red), g1 = block_sum(G1[q], s_red);
-          if (threadIdx.x == 0) {
-            float* row = (q == CUBE_QMAX) ? MLd : a.MB + ((size_t)q * a.nB + b) * a.nk;
-            row[j0] += g0;
-            row[j1] += g1;
-          }
-        }
-      }
-      jfirst = min(jfirst, (int)j0);
-      jlast = max(jlast, (int)j1);
-    }
-    p_lo = p_hi;
-    ++jj;
-  }
-  const float Nb = block_sum(Nsum, s_red), Cb = block_sum(Csum, s_red);
-  if (threadIdx.x == 0) {
-    a.N[b] = Nb;
-    a.C[b] = Cb;
+  if (threadIdx.x == 64 * BBM_WAVES - 1) {
+    a.N[b] = Nacc;
+    a.C[b] = Cacc;
     a.jrange[b] = make_int2(jfirst == 0x7fffffff ? 0 : jfirst, jlast);
+#if CUBE_ABLATE & 256
+    T3 = wall_clock64();  // 100 MHz ticks
+    a.N[b] = (float)(T1 - T0); a.C[b] = (float)(T2 - T0);
+    a.jrange[b] = make_int2((int)(T3 - T0), (int)(jj_last - jj_first + 1));
+#endif
+  }
+}
+
+template <int KIND>
+static void launch_basis_moments(const BasisArgs& a, hipStream_t stream) {
+  const dim3 grid(a.nB), block(64 * BBM_WAVES);
+  switch (a.Q) {
+    case 1: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 1>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 2>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 3>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 4>), grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 5>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 6>), grid, block, 0, stream, a); break;
   }
 }
 
@@ -1022,67 +1185,249 @@ extern "C" int rtx_band_basis_moments(int kind, const rtx_grid* grid, const floa
   for (int q = 0; q < CUBE_QMAX; ++q)
     for (int d = 0; d < CUBE_QMAX; ++d) a.coef[q][d] = (q < Q && d < Q) ? basis_coef_h[q * Q + d] : 0.f;
   a.N = N_out; a.C = C_out; a.MLd = MLd_out; a.MB = MB_out; a.jrange = reinterpret_cast<int2*>(jrange_out);
-  hipLaunchKernelGGL(band_basis_moments_kernel, dim3(nB), dim3(256), 0, (hipStream_t)stream, a);
+  if (kind == 0) launch_basis_moments<0>(a, (hipStream_t)stream); else launch_basis_moments<1>(a, (hipStream_t)stream);
+  RTX_LAUNCH_CHECK();
+  return 0;
+}
+
+// The (Q + 1) contractions of one cube in ONE launch: M[n_stack][nB][nk] (rows 0..Q-1: MB[q], row Q: MLd) with the endmember
+// knot spectra E[nk][nE] -> tab[nE][n_stack][nB], the layout pixel_cube_kernel reads with lane = band. lane = endmember.
+struct MixStackArgs {
+  const float* M;
+  const int2* jrange;
+  int nB, n_stack;
+  long long nk, nE;
+  const float* E;
+  float* tab;
+};
+
+__global__ __launch_bounds__(64) void band_mix_stacked_kernel(MixStackArgs a) {
+  const int b = blockIdx.x;
+  const long long k = (long long)blockIdx.y * 64 + threadIdx.x;
+  if (k >= a.nE) return;
+  const int2 jr = a.jrange[b];
+  float acc[CUBE_QMAX + 1];
+#pragma unroll
+  for (int s = 0; s <= CUBE_QMAX; ++s) acc[s] = 0.f;
+  for (int j = jr.x; j <= jr.y; ++j) {
+    const float e = a.E[(size_t)j * a.nE + k];
+#pragma unroll
+    for (int s = 0; s <= CUBE_QMAX; ++s)
+      if (s < a.n_stack) acc[s] = fmaf(a.M[((size_t)s * a.nB + b) * a.nk + j], e, acc[s]);
+  }
+#pragma unroll
+  for (int s = 0; s <= CUBE_QMAX; ++s)
+    if (s < a.n_stack) a.tab[((size_t)k * a.n_stack + s) * a.nB + b] = acc[s];
+}
+
+extern "C" int rtx_band_mix_stacked(const float* M, const int32_t* jrange, int nB, int n_stack, int64_t nk, const float* E,
+                                    int64_t nE, float* tab, void* stream) {
+  if (nB < 0 || nE < 0 || nk < 1) RTX_FAIL("bad size");
+  if (n_stack < 1 || n_stack > CUBE_QMAX + 1) RTX_FAIL("n_stack=%d outside [1,%d]", n_stack, CUBE_QMAX + 1);
+  if (nB == 0 || nE == 0) return 0;
+  if (!M || !jrange || !E || !tab) RTX_FAIL("a required pointer is NULL");
+  MixStackArgs a;
+  a.M = M; a.jrange = reinterpret_cast<const int2*>(jrange); a.nB = nB; a.n_stack = n_stack; a.nk = nk; a.nE = nE; a.E = E; a.tab = tab;
+  hipLaunchKernelGGL(band_mix_stacked_kernel, dim3(nB, (unsigned)((nE + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
   RTX_LAUNCH_CHECK();
   return 0;
 }
 
 struct CubeArgs {
-  int nB, Q, nEnd, nMix;
+  int nB, nEnd, nMix;
   long long nPix;
   const double* centre;
   const double* sigma;
   float node_span;
   float s_node[CUBE_QMAX];
-  const float *N, *C, *ALd, *AB;  // ALd [nB][nEnd], AB [Q][nB][nEnd]
-  const int* kidx;                // [nPix][nMix]
-  const float* frac;              // [nPix][nMix]
-  const double* Tpix;             // [nPix]
-  float* cube;                    // [nB][nPix]
+  const float *N, *C;
+  const float* tab;    // [nEnd][Q+1][nB]: rows 0..Q-1 the Planck-node tables AB[q], row Q the Ld table ALd
+  const int* kidx;     // [nPix][nMix]
+  const float* frac;   // [nPix][nMix]
+  const double* Tpix;  // [nPix]
+  float* cube;         // [nB][nPix]
 };
 
-// lanes <-> pixels (coalesced along the pixel axis of the cube), one band per blockIdx.y
-__global__ __launch_bounds__(256) void pixel_cube_kernel(CubeArgs a) {
-  const int b = blockIdx.y;
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.nPix) return;
-  const double c = a.centre[b], Rn = (double)a.node_span * a.sigma[b];
-  const double c2l2e_over_T = 100.0 * RT_C2 * 1.4426950408889634 / a.Tpix[p];
-  float Bq[CUBE_QMAX];
+// lane = band, a wave walks pixels. Everything a pixel owns (temperature, mixture) is wave-uniform -- scalar loads, one fp64
+// division per pixel and workgroup -- and everything a band owns (node abscissae, c1 nu^3, C_b, 1/N_b) lives in the lane's
+// registers for the 256 pixels of the workgroup; the tables are read with consecutive lanes on consecutive words out of LDS
+// (or, when 64 bands x nEnd x (Q+1) words do not fit, out of L1/L2 with the same indexing). Round 2 had lane = pixel and one
+// band per workgroup: 18 gathers, five fp64 Planck exponents and an fp64 division per (band, pixel) -- 146 us for C5, where
+// the cube itself is 8 us of HBM writes.
+// Planck at node q: log2 of the exponential = nu_q kT with kT = 100 c2 log2(e) / T_p.  nu_q = c_b + R_b s_q, so it is
+// c_b kT (fp64: this is where the digits are) + (R_b s_q) kT (fp32: |R_b kT| is a few hundredths for a MAKO band, its
+// rounding error 1e-9 of the exponent); the integer part of c_b kT is split off once per (band, pixel).
+// The (band, pixel) values go through a 64 x 64 LDS tile so that the cube is written in 256-byte rows along the pixel axis.
+#define CUBE_PB 256  // pixels per workgroup
+#define CUBE_STAGE_MIX 4  // mixtures of up to this many endmembers ride in the lanes (16 pixels x nMix <= 64)
+
+// One (band, pixel) value. FAST: every node of every (band, pixel) of the workgroup has exponent >= 1.5 (checked once per
+// workgroup), the exponential in fp32 from the two-float product; otherwise per pixel, with planck_f32's fp64 branch.
+template <int Q, bool FAST>
+__device__ __forceinline__ void cube_planck(float (&Bq)[Q], const float (&c1x3)[Q], const float (&dq)[Q], float c_hi, float c_lo,
+                                            float dmax, float2 kf, double kT, double c, double Rn, const float* s_node) {
+  // c_b kT in two-float arithmetic: c = c_hi + c_lo, kT = k_hi + k_lo; c_hi k_hi = pr + er exactly (FMA), and its integer
+  // part leaves pr exactly
+  const float pr = c_hi * kf.x, er = fmaf(c_hi, kf.x, -pr);
+  if (FAST || __ballot(pr - dmax * kf.x < 1.5f) == 0) {
+    const float n = rintf(pr);
+    const float f0 = (pr - n) + fmaf(c_hi, kf.y, fmaf(c_lo, kf.x, er));
+    const int ni = (int)n;
 #pragma unroll
-  for (int q = 0; q < CUBE_QMAX; ++q) {
-    if (q < a.Q) {
-      const double x = c + Rn * (double)a.s_node[q];
-      const double x100 = x * 100.0;
-      Bq[q] = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, c2l2e_over_T);
-    } else {
-      Bq[q] = 0.f;
+    for (int q = 0; q < Q; ++q) {
+      const float e = ldexpf(__builtin_amdgcn_exp2f(fmaf(dq[q], kf.x, f0)), ni);  // inf above 2^128: B -> 0
+      Bq[q] = c1x3[q] * __builtin_amdgcn_rcpf(e - 1.0f);
+    }
+  } else {  // far-infrared nodes: expm1 in fp64 (planck_f32's small-argument branch)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const double x = c + Rn * (double)s_node[q], x100 = x * 100.0;
+      Bq[q] = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, kT);
     }
   }
-  float acc = a.C[b];
-  for (int m = 0; m < a.nMix; ++m) {
-    const int k = a.kidx[p * a.nMix + m];
-    float t = -a.ALd[(size_t)b * a.nEnd + k];
-#pragma unroll
-    for (int q = 0; q < CUBE_QMAX; ++q)
-      if (q < a.Q) t = fmaf(Bq[q], a.AB[((size_t)q * a.nB + b) * a.nEnd + k], t);
-    acc = fmaf(a.frac[p * a.nMix + m], t, acc);
+}
+
+template <int Q, bool TAB_LDS, bool STAGED>
+__global__ __launch_bounds__(256) void pixel_cube_kernel(CubeArgs a) {
+  extern __shared__ float s_tab[];  // TAB_LDS: [nEnd][Q+1][64]
+  __shared__ float s_tile[64][65];
+  __shared__ double s_kT[CUBE_PB];
+  __shared__ float2 s_kTf[CUBE_PB];  // kT as hi + lo floats
+  __shared__ float s_kmin[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b0 = blockIdx.y * 64;
+  const int b = min(b0 + lane, a.nB - 1);
+  const long long p0 = (long long)blockIdx.x * CUBE_PB;
+  const int n_pl = (int)min((long long)CUBE_PB, a.nPix - p0);  // pixels of this workgroup (>= 1)
+  const int nMix = a.nMix;
+  {
+    const double kT = 100.0 * RT_C2 * 1.4426950408889634 / a.Tpix[p0 + min((int)threadIdx.x, n_pl - 1)];
+    s_kT[threadIdx.x] = kT;
+    const float hi = (float)kT;
+    s_kTf[threadIdx.x] = make_float2(hi, (float)(kT - (double)hi));
+    float m = hi == hi ? hi : -1.0f;  // NaN temperature -> the per-pixel path
+    for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+    if (lane == 0) s_kmin[wave] = m;
   }
-  a.cube[(size_t)b * a.nPix + p] = acc / a.N[b];
+  // the mixtures of this wave's 16 pixels of a round, one (pixel, endmember slot) per lane, loaded one round ahead: the loop
+  // below takes them out of the lanes with v_readlane
+  const int st_i = STAGED ? min(lane / nMix, 15) : 0, st_m = STAGED ? lane - (lane / nMix) * nMix : 0;
+  int kv = 0, kv_n = 0;
+  float fv = 0.f, fv_n = 0.f;
+  if (STAGED) {
+    const long long p = p0 + min(wave * 16 + st_i, n_pl - 1);
+    kv_n = a.kidx[p * nMix + st_m];
+    fv_n = a.frac[p * nMix + st_m];
+  }
+  if (TAB_LDS && !(CUBE_ABLATE & 64)) {
+    const int n = a.nEnd * (Q + 1) * 64;
+    for (int i = threadIdx.x; i < n; i += 256) s_tab[i] = a.tab[(size_t)(i >> 6) * a.nB + min(b0 + (i & 63), a.nB - 1)];
+  }
+  const double c = a.centre[b], Rn = (double)a.node_span * a.sigma[b];
+  float c1x3[Q], dq[Q];
+  float dmax = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const double x100 = (c + Rn * (double)a.s_node[q]) * 100.0;
+    c1x3[q] = (float)(RT_C1 * (x100 * x100 * x100) * 1e4);
+    dq[q] = (float)(Rn * (double)a.s_node[q]);
+    dmax = fmaxf(dmax, fabsf(dq[q]));
+  }
+  const float c_hi = (float)c, c_lo = (float)(c - (double)c_hi);
+  const float Cb = a.C[b], invN = 1.0f / a.N[b];  // N = 0 -> 0 * inf = NaN, as the unfused path
+  const float* tab = TAB_LDS ? s_tab + lane : a.tab + b;
+  const size_t ts = TAB_LDS ? 64 : (size_t)a.nB;  // words between a table's rows
+  const int k_max = a.nEnd - 1;
+  __syncthreads();
+  // the smallest exponent any node of this workgroup can have: (c - dmax) * the smallest kT, with a margin for the roundings
+  const float kmin = fminf(fminf(s_kmin[0], s_kmin[1]), fminf(s_kmin[2], s_kmin[3]));
+  const bool fast = __syncthreads_and((c_hi - dmax) * kmin >= 1.51f && dmax < c_hi);
+  for (int g = 0; g < CUBE_PB / 64; ++g) {
+    if (g * 64 < n_pl) {  // uniform over the workgroup
+      kv = kv_n; fv = fv_n;
+      if (STAGED && (g + 1) * 64 < n_pl) {
+        const long long p = p0 + min((g + 1) * 64 + wave * 16 + st_i, n_pl - 1);
+        kv_n = a.kidx[p * nMix + st_m];
+        fv_n = a.frac[p * nMix + st_m];
+      }
+      for (int i = 0; i < 16; ++i) {  // (unrolled by 2 or 4: the same 46-47 us)
+        const int pl = wave * 16 + i;
+        const int px = min(g * 64 + pl, n_pl - 1);  // past the end: the last pixel again, not written
+        float Bq[Q];
+        if (CUBE_ABLATE & 16) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) Bq[q] = c1x3[q] * s_kTf[px].x;
+        } else if (fast) {
+          cube_planck<Q, true>(Bq, c1x3, dq, c_hi, c_lo, dmax, s_kTf[px], 0.0, c, Rn, a.s_node);
+        } else {
+          cube_planck<Q, false>(Bq, c1x3, dq, c_hi, c_lo, dmax, s_kTf[px], s_kT[px], c, Rn, a.s_node);
+        }
+        float acc = Cb;
+        if (CUBE_ABLATE & 32) acc += Bq[0] + Bq[Q - 1] + Bq[Q / 2]; else
+        for (int m = 0; m < nMix; ++m) {
+          int k;
+          float fr;
+          if (STAGED) {
+            k = __builtin_amdgcn_readlane(kv, i * nMix + m);
+            fr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fv), i * nMix + m));
+          } else {
+            k = a.kidx[(p0 + px) * nMix + m];
+            fr = a.frac[(p0 + px) * nMix + m];
+          }
+          k = min(max(k, 0), k_max);  // an index outside the table must not leave it
+          const float* row = tab + (size_t)k * (Q + 1) * ts;
+          float t = -row[Q * ts];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) t = fmaf(Bq[q], row[q * ts], t);
+          acc = fmaf(fr, t, acc);
+        }
+        s_tile[lane][pl] = acc * invN;
+      }
+    }
+    __syncthreads();
+    if (g * 64 + lane < n_pl) {
+      float* dst = a.cube + (size_t)b0 * a.nPix + p0 + g * 64 + lane;
+#pragma unroll 4
+      for (int r = wave * 16; r < wave * 16 + 16; ++r)
+        if (b0 + r < a.nB && (!(CUBE_ABLATE & 128) || s_tile[r][lane] == 123.f)) dst[(size_t)r * a.nPix] = s_tile[r][lane];
+    }
+    __syncthreads();
+  }
+}
+
+template <int Q>
+static void launch_pixel_cube(const CubeArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)((a.nPix + CUBE_PB - 1) / CUBE_PB), (unsigned)((a.nB + 63) / 64));
+  const size_t tab_bytes = (size_t)a.nEnd * (Q + 1) * 64 * sizeof(float);
+  const bool staged = a.nMix <= CUBE_STAGE_MIX;
+  if (tab_bytes <= 56 * 1024) {
+    if (staged) hipLaunchKernelGGL((pixel_cube_kernel<Q, true, true>), grid, dim3(256), tab_bytes, stream, a);
+    else hipLaunchKernelGGL((pixel_cube_kernel<Q, true, false>), grid, dim3(256), tab_bytes, stream, a);
+  } else {
+    if (staged) hipLaunchKernelGGL((pixel_cube_kernel<Q, false, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((pixel_cube_kernel<Q, false, false>), grid, dim3(256), 0, stream, a);
+  }
 }
 
 extern "C" int rtx_pixel_cube(int nB, int Q, const double* centre, const double* sigma, double node_span, const float* s_node_h,
-                              const float* N, const float* C, const float* ALd, const float* AB, int nEnd, int64_t nPix,
-                              int nMix, const int32_t* kidx, const float* frac, const double* Tpix, float* cube, void* stream) {
+                              const float* N, const float* C, const float* tab, int nEnd, int64_t nPix, int nMix,
+                              const int32_t* kidx, const float* frac, const double* Tpix, float* cube, void* stream) {
   if (Q < 1 || Q > CUBE_QMAX) RTX_FAIL("Q=%d outside [1,%d]", Q, CUBE_QMAX);
   if (nB < 0 || nPix < 0 || nEnd < 1 || nMix < 1) RTX_FAIL("bad size");
   if (nB == 0 || nPix == 0) return 0;
-  if (!centre || !sigma || !s_node_h || !N || !C || !ALd || !AB || !kidx || !frac || !Tpix || !cube) RTX_FAIL("a required pointer is NULL");
+  if (!centre || !sigma || !s_node_h || !N || !C || !tab || !kidx || !frac || !Tpix || !cube) RTX_FAIL("a required pointer is NULL");
   CubeArgs a;
-  a.nB = nB; a.Q = Q; a.nEnd = nEnd; a.nMix = nMix; a.nPix = nPix; a.centre = centre; a.sigma = sigma; a.node_span = (float)node_span;
+  a.nB = nB; a.nEnd = nEnd; a.nMix = nMix; a.nPix = nPix; a.centre = centre; a.sigma = sigma; a.node_span = (float)node_span;
   for (int q = 0; q < CUBE_QMAX; ++q) a.s_node[q] = q < Q ? s_node_h[q] : 0.f;
-  a.N = N; a.C = C; a.ALd = ALd; a.AB = AB; a.kidx = kidx; a.frac = frac; a.Tpix = Tpix; a.cube = cube;
-  hipLaunchKernelGGL(pixel_cube_kernel, dim3((unsigned)((nPix + 255) / 256), nB), dim3(256), 0, (hipStream_t)stream, a);
+  a.N = N; a.C = C; a.tab = tab; a.kidx = kidx; a.frac = frac; a.Tpix = Tpix; a.cube = cube;
+  switch (Q) {
+    case 1: launch_pixel_cube<1>(a, (hipStream_t)stream); break;
+    case 2: launch_pixel_cube<2>(a, (hipStream_t)stream); break;
+    case 3: launch_pixel_cube<3>(a, (hipStream_t)stream); break;
+    case 4: launch_pixel_cube<4>(a, (hipStream_t)stream); break;
+    case 5: launch_pixel_cube<5>(a, (hipStream_t)stream); break;
+    default: launch_pixel_cube<6>(a, (hipStream_t)stream); break;
+  }
   RTX_LAUNCH_CHECK();
   return 0;
 }

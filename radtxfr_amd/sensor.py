@@ -78,7 +78,34 @@ def chebyshev_lagrange(Q):
     return s, coef
 
 
-def hsi_cube(grid, tau, La, Ld, Xk, endmembers, kidx, frac, Tpix, resFactor=2, band_slice=None, Q=5, bands=None):
+_CUBE_PLANS = {}  # spectra-independent set-up of hsi_cube (band list, knots and node tables on the device), a few entries
+_CUBE_PLANS_MAX = 8
+
+
+def _cube_plan(grid, Xk, resFactor, band_slice, Q, bands, dev):
+    """Everything hsi_cube needs that does not depend on the spectra or the scene: the band list of rt.ILS_MAKO, its centres
+    and widths and the knot axis as device tensors, the Chebyshev nodes and Lagrange coefficients. A scene generator calls
+    hsi_cube once per atmosphere / scene with the same axis, knots and bands; building these took as long as the kernels."""
+    Xk = np.ascontiguousarray(Xk, dtype=np.float64)
+    key = (grid.x_at(0), grid.step, grid.n, resFactor, band_slice, Q, str(dev), Xk.tobytes(),
+           None if bands is None else tuple(np.ascontiguousarray(v, dtype=np.float64).tobytes() for v in bands))
+    plan = _CUBE_PLANS.get(key)
+    if plan is None:
+        X_out, centre, sigma = bands if bands is not None else mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
+        if band_slice is not None:
+            X_out, centre, sigma = (v[band_slice[0]:band_slice[1]] for v in (X_out, centre, sigma))
+        s_nodes, coef = chebyshev_lagrange(Q)
+        plan = {"X_out": np.array(X_out, dtype=np.float64), "coef32": np.ascontiguousarray(coef, dtype=np.float32),
+                "sn32": np.ascontiguousarray(s_nodes, dtype=np.float32), "Xk_d": torch.as_tensor(Xk, device=dev),
+                "c_d": torch.as_tensor(np.ascontiguousarray(centre, dtype=np.float64), device=dev),
+                "s_d": torch.as_tensor(np.ascontiguousarray(sigma, dtype=np.float64), device=dev)}
+        if len(_CUBE_PLANS) >= _CUBE_PLANS_MAX:
+            _CUBE_PLANS.pop(next(iter(_CUBE_PLANS)))
+        _CUBE_PLANS[key] = plan
+    return plan
+
+
+def hsi_cube(grid, tau, La, Ld, Xk, endmembers, kidx, frac, Tpix, resFactor=2, band_slice=None, Q=4, bands=None):
     """Config C5: band radiances of an HSI cube whose pixels each have an emissivity mixture and a surface
     temperature of their own (LWIR_HSI_Generator.py:151-167), from monochromatic tau/La/Ld through the
     triangle ILS (rt.ILS_MAKO with resFactor).
@@ -87,38 +114,31 @@ def hsi_cube(grid, tau, La, Ld, Xk, endmembers, kidx, frac, Tpix, resFactor=2, b
     Tpix [nPix] float64 -- device tensors. band_slice: (b0, b1) to compute only a band-aligned shard.
     bands = (X_out, centre, sigma): explicit band list (mako_bands() of the FULL spectral axis) when `grid` is only the
     wavenumber shard under those bands (dist.hsi_cube_from_atmosphere); default: the bands inside `grid`.
-    Returns (X_out [nB] NumPy, cube [nB][nPix] float32 device)."""
+    Returns (X_out [nB] NumPy, cube [nB][nPix] float32 device). Three launches: rtx_band_basis_moments (the one pass over
+    the monochromatic arrays), rtx_band_mix_stacked (its Q + 1 moment arrays x the endmember knots), rtx_pixel_cube."""
     lib = _lib.load()
     dev = tau.device
-    X_out, centre, sigma = bands if bands is not None else mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
-    if band_slice is not None:
-        X_out, centre, sigma = X_out[band_slice[0]:band_slice[1]], centre[band_slice[0]:band_slice[1]], sigma[band_slice[0]:band_slice[1]]
+    plan = _cube_plan(grid, Xk, resFactor, None if band_slice is None else (int(band_slice[0]), int(band_slice[1])), int(Q), bands, dev)
+    X_out = plan["X_out"].copy()
     nB, nk, nEnd = X_out.size, len(Xk), endmembers.shape[1]
     nPix, nMix = kidx.shape
     assert endmembers.dtype == torch.float32 and endmembers.shape[0] == nk
     endmembers = endmembers.contiguous()
     assert kidx.dtype == torch.int32 and frac.dtype == torch.float32 and Tpix.dtype == torch.float64
-    s_nodes, coef = chebyshev_lagrange(Q)
-    coef32 = np.ascontiguousarray(coef, dtype=np.float32)
-    sn32 = np.ascontiguousarray(s_nodes, dtype=np.float32)
-    Xk_d = torch.as_tensor(np.asarray(Xk, dtype=np.float64), device=dev)
-    c_d, s_d = torch.as_tensor(centre, device=dev), torch.as_tensor(sigma, device=dev)
     f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-    N, Cb, MLd, MB = f32(nB), f32(nB), f32(nB, nk), f32(Q, nB, nk)
-    jr = torch.empty((nB, 2), dtype=torch.int32, device=dev)
-    ALd, AB = f32(nB, nEnd), f32(Q, nB, nEnd)
     cube = f32(nB, nPix)
-    p = lambda t: C.c_void_p(t.data_ptr())
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     if nB == 0:
         return X_out, cube
-    _lib.check(lib.rtx_band_basis_moments(0, grid.byref(), p(tau), p(La), p(Ld), p(Xk_d), nk, nB, p(c_d), p(s_d), Q,
-                                          coef32.ctypes.data_as(C.c_void_p), 1.0, p(N), p(Cb), p(MLd), p(MB), p(jr), st))
-    _lib.check(lib.rtx_band_mix(None, None, p(MLd), p(jr), nB, nk, p(endmembers), nEnd, p(ALd), st))
-    for q in range(Q):
-        _lib.check(lib.rtx_band_mix(None, None, p(MB[q]), p(jr), nB, nk, p(endmembers), nEnd, p(AB[q]), st))
-    _lib.check(lib.rtx_pixel_cube(nB, Q, p(c_d), p(s_d), 1.0, sn32.ctypes.data_as(C.c_void_p), p(N), p(Cb), p(ALd), p(AB), nEnd,
-                                  nPix, nMix, p(kidx.contiguous()), p(frac.contiguous()), p(Tpix.contiguous()), p(cube), st))
+    N, Cb, M = f32(nB), f32(nB), f32(Q + 1, nB, nk)  # M[0..Q-1]: the Planck-node basis moments, M[Q]: the Ld moment
+    jr = torch.empty((nB, 2), dtype=torch.int32, device=dev)
+    tab = f32(nEnd, Q + 1, nB)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rtx_band_basis_moments(0, grid.byref(), p(tau), p(La), p(Ld), p(plan["Xk_d"]), nk, nB, p(plan["c_d"]), p(plan["s_d"]), Q,
+                                          plan["coef32"].ctypes.data_as(C.c_void_p), 1.0, p(N), p(Cb), p(M[Q]), p(M), p(jr), st))
+    _lib.check(lib.rtx_band_mix_stacked(p(M), p(jr), nB, Q + 1, nk, p(endmembers), nEnd, p(tab), st))
+    _lib.check(lib.rtx_pixel_cube(nB, Q, p(plan["c_d"]), p(plan["s_d"]), 1.0, plan["sn32"].ctypes.data_as(C.c_void_p), p(N), p(Cb), p(tab),
+                                  nEnd, nPix, nMix, p(kidx.contiguous()), p(frac.contiguous()), p(Tpix.contiguous()), p(cube), st))
     return X_out, cube
 
 
