@@ -1655,3 +1655,43 @@ def test_c5_full_size_end_to_end_vs_oracle(rt):
     assert inside.sum() >= 3
     got = cube.cpu().numpy()[:, pix][inside]
     assert rel_err(got, Lr[inside]) <= TOL_L, rel_err(got, Lr[inside])
+
+
+def test_c5_cube_kernel_paths_vs_oracle(rt):
+    """The paths of the round-3 cube kernels the C5 configuration does not reach (LWIR_HSI_Generator.py:151-167 + rt.ILS_MAKO):
+    a pixel count that ends inside a workgroup and inside a round of 64; mixtures of 6 endmembers (read per pixel, not staged
+    in the lanes) and of 3; 400 endmembers (tables too large for LDS: read from global memory); Q = 3, 5, 6; pixels at
+    1200-1500 K, where the Planck exponent of a MAKO band drops below 1.5 and the fp64 small-argument branch runs (decided
+    per workgroup, then per pixel); a knot axis denser than the grid's bands (rounds of more than 16 intervals per band)."""
+    import torch
+    from radtxfr_amd import engine, sensor
+    rng = np.random.default_rng(20261101)
+    dev = torch.device("cuda")
+    f32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32), device=dev)
+    grid = engine.Grid(760.0, 1320.0, 28000)
+    X = grid.axis()
+    tau = 0.5 + 0.45 * np.sin(X / 11.0)
+    La = 2.0 + np.cos(X / 23.0)
+    Ld = 4.0 + 2.0 * np.sin(X / 9.0)
+    cases = [dict(nk=60, nEnd=400, nMix=6, nPix=300, Q=4, hot=True),
+             dict(nk=60, nEnd=7, nMix=3, nPix=333, Q=3, hot=True),
+             dict(nk=2500, nEnd=5, nMix=2, nPix=65, Q=5, hot=False),
+             dict(nk=60, nEnd=9, nMix=5, nPix=257, Q=6, hot=False)]
+    for cs in cases:
+        Xk = np.sort(rng.uniform(750.0, 1330.0, cs["nk"]))
+        em = rng.uniform(0.05, 1.0, (cs["nk"], cs["nEnd"]))
+        kidx = rng.integers(0, cs["nEnd"], (cs["nPix"], cs["nMix"])).astype(np.int32)
+        frac = rng.uniform(0.0, 1.0, (cs["nPix"], cs["nMix"]))
+        frac /= frac.sum(1, keepdims=True)
+        Tp = rng.uniform(270.0, 330.0, cs["nPix"])
+        if cs["hot"]:
+            Tp[rng.integers(0, cs["nPix"], 12)] = rng.uniform(1200.0, 1500.0, 12)
+            Tp[-1] = 1450.0  # the last, partial workgroup takes the per-pixel path too
+        xo, cube = sensor.hsi_cube(grid, f32(tau), f32(La), f32(Ld), Xk, f32(em), torch.as_tensor(kidx, device=dev), f32(frac),
+                                   torch.as_tensor(Tp, device=dev), resFactor=2, Q=cs["Q"])
+        em_hi = np.stack([np.interp(X, Xk, em[:, k]) for k in range(cs["nEnd"])], axis=1)
+        em_p = np.einsum("pm,xpm->xp", frac, em_hi[:, kidx])
+        L = tau[:, None] * (em_p * ref.planckian(X, Tp) + (1 - em_p) * Ld[:, None]) + La[:, None]
+        xr, Lr = ref.ILS_MAKO(X, L, resFactor=2)
+        assert np.array_equal(xo, xr) and cube.shape == Lr.shape, cs
+        assert rel_err(cube.cpu().numpy(), Lr) <= TOL_L, cs
