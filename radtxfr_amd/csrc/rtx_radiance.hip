@@ -1400,7 +1400,7 @@ static void launch_pixel_cube(const CubeArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)((a.nPix + CUBE_PB - 1) / CUBE_PB), (unsigned)((a.nB + 63) / 64));
   const size_t tab_bytes = (size_t)a.nEnd * (Q + 1) * 64 * sizeof(float);
   const bool staged = a.nMix <= CUBE_STAGE_MIX;
-  if (tab_bytes <= 56 * 1024) {
+  if (tab_bytes <= 40 * 1024) {  // + 21 KB of static LDS: within the 64 KB every HIP launch may ask for
     if (staged) hipLaunchKernelGGL((pixel_cube_kernel<Q, true, true>), grid, dim3(256), tab_bytes, stream, a);
     else hipLaunchKernelGGL((pixel_cube_kernel<Q, true, false>), grid, dim3(256), tab_bytes, stream, a);
   } else {

@@ -6,6 +6,7 @@ ILS needs an (nS,nX,nB) temporary (1.4 TB at 2000 spectra); here the monochromat
 (560 k wavenumbers x 2000 spectra x 4 B = 4.5 GB) and the order "radiance first, ILS second" is exact.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -80,6 +81,7 @@ def chebyshev_lagrange(Q):
 
 _CUBE_PLANS = {}  # spectra-independent set-up of hsi_cube (band list, knots and node tables on the device), a few entries
 _CUBE_PLANS_MAX = 8
+_CUBE_PLANS_LOCK = threading.Lock()
 
 
 def _cube_plan(grid, Xk, resFactor, band_slice, Q, bands, dev):
@@ -89,7 +91,8 @@ def _cube_plan(grid, Xk, resFactor, band_slice, Q, bands, dev):
     Xk = np.ascontiguousarray(Xk, dtype=np.float64)
     key = (grid.x_at(0), grid.step, grid.n, resFactor, band_slice, Q, str(dev), Xk.tobytes(),
            None if bands is None else tuple(np.ascontiguousarray(v, dtype=np.float64).tobytes() for v in bands))
-    plan = _CUBE_PLANS.get(key)
+    with _CUBE_PLANS_LOCK:
+        plan = _CUBE_PLANS.get(key)
     if plan is None:
         X_out, centre, sigma = bands if bands is not None else mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
         if band_slice is not None:
@@ -99,9 +102,10 @@ def _cube_plan(grid, Xk, resFactor, band_slice, Q, bands, dev):
                 "sn32": np.ascontiguousarray(s_nodes, dtype=np.float32), "Xk_d": torch.as_tensor(Xk, device=dev),
                 "c_d": torch.as_tensor(np.ascontiguousarray(centre, dtype=np.float64), device=dev),
                 "s_d": torch.as_tensor(np.ascontiguousarray(sigma, dtype=np.float64), device=dev)}
-        if len(_CUBE_PLANS) >= _CUBE_PLANS_MAX:
-            _CUBE_PLANS.pop(next(iter(_CUBE_PLANS)))
-        _CUBE_PLANS[key] = plan
+        with _CUBE_PLANS_LOCK:
+            if len(_CUBE_PLANS) >= _CUBE_PLANS_MAX:
+                _CUBE_PLANS.pop(next(iter(_CUBE_PLANS)))
+            _CUBE_PLANS[key] = plan
     return plan
 
 

@@ -1660,7 +1660,8 @@ def test_c5_full_size_end_to_end_vs_oracle(rt):
 def test_c5_cube_kernel_paths_vs_oracle(rt):
     """The paths of the round-3 cube kernels the C5 configuration does not reach (LWIR_HSI_Generator.py:151-167 + rt.ILS_MAKO):
     a pixel count that ends inside a workgroup and inside a round of 64; mixtures of 6 endmembers (read per pixel, not staged
-    in the lanes) and of 3; 400 endmembers (tables too large for LDS: read from global memory); Q = 3, 5, 6; pixels at
+    in the lanes) and of 3 and 4; 400 endmembers (tables too large for LDS: read from global memory) and 31 (the largest
+    tables that still go to LDS); Q = 3, 5, 6; pixels at
     1200-1500 K, where the Planck exponent of a MAKO band drops below 1.5 and the fp64 small-argument branch runs (decided
     per workgroup, then per pixel); a knot axis denser than the grid's bands (rounds of more than 16 intervals per band)."""
     import torch
@@ -1676,7 +1677,8 @@ def test_c5_cube_kernel_paths_vs_oracle(rt):
     cases = [dict(nk=60, nEnd=400, nMix=6, nPix=300, Q=4, hot=True),
              dict(nk=60, nEnd=7, nMix=3, nPix=333, Q=3, hot=True),
              dict(nk=2500, nEnd=5, nMix=2, nPix=65, Q=5, hot=False),
-             dict(nk=60, nEnd=9, nMix=5, nPix=257, Q=6, hot=False)]
+             dict(nk=60, nEnd=9, nMix=5, nPix=257, Q=6, hot=False),
+             dict(nk=60, nEnd=31, nMix=4, nPix=130, Q=4, hot=False)]  # 39.7 KB of tables: the largest LDS case
     for cs in cases:
         Xk = np.sort(rng.uniform(750.0, 1330.0, cs["nk"]))
         em = rng.uniform(0.05, 1.0, (cs["nk"], cs["nEnd"]))
