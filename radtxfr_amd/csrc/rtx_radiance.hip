@@ -738,106 +738,9 @@ extern "C" int rtx_interp_knots(const rtx_grid* grid, const double* X, int64_t n
 //   L_b,k = ( C_b + sum_j M[b][j] E[j][k] ) / N_b,
 //   N_b = sum_i w_i,  C_b = sum_i w_i (tau_i Ld_i + La_i),  M[b][j] = sum over the two knot intervals touching j of
 //   w_i tau_i (B_i - Ld_i) times the hat function of knot j at nu_i.
-// rtx_band_moments does the monochromatic pass once (wavefront reductions per knot interval, fixed order:
-// deterministic); rtx_band_mix is the tiny [nB x nk] x [nk x nE] contraction restricted to each band's knots.
-struct MomArgs {
-  int kind;
-  GridDev g;
-  long long nx;
-  const float *tau, *La, *Ld;
-  double c2l2e_over_T;  // 100*c2*log2(e)/Ts
-  const double* Xk;
-  long long nk;
-  int nB;
-  const double* centre;
-  const double* sigma;
-  float* N;      // [nB]
-  float* C;      // [nB]
-  float* M;      // [nB][nk]
-  int2* jrange;  // [nB] first / last knot with a non-zero M
-};
-
-__device__ __forceinline__ float block_sum(float v, float* s_red) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
-
-// first grid index with X[i] >= v (uniform grid only)
-__device__ long long grid_lower_bound(const GridDev& g, long long n, double v) {
-  long long lo = 0, hi = n;
-  while (lo < hi) {
-    const long long mid = (lo + hi) >> 1;
-    if (grid_x(g, g.offset + mid) >= v) hi = mid; else lo = mid + 1;
-  }
-  return lo;
-}
-
-__global__ __launch_bounds__(256) void band_moments_kernel(MomArgs a) {
-  __shared__ float s_red[4];
-  const int b = blockIdx.x;
-  const double c = a.centre[b], s = a.sigma[b];
-  const double R = a.kind == 0 ? s : 14.0 * s;
-  // support: X > c-R and X < c+R  (open interval, like tri() and the ILS kernels)
-  long long lo = grid_lower_bound(a.g, a.nx, c - R);
-  while (lo < a.nx && !(grid_x(a.g, a.g.offset + lo) > c - R)) ++lo;
-  const long long hi = grid_lower_bound(a.g, a.nx, c + R);
-  float* Mrow = a.M + (size_t)b * a.nk;
-  for (long long j = threadIdx.x; j < a.nk; j += blockDim.x) Mrow[j] = 0.f;
-  float Nsum = 0.f, Csum = 0.f;  // per-thread partials over the whole band
-  int jfirst = 0x7fffffff, jlast = -1;
-  // knot intervals jj = -1 (left of the first knot) .. nk-1 (right of the last): np.interp holds the end values
-  long long p_lo = lo;
-  // first interval that can contain X[lo]: jj = (#knots <= X[lo]) - 1
-  long long jj;
-  {
-    const double x_first = lo < a.nx ? grid_x(a.g, a.g.offset + lo) : 0.0;
-    long long l2 = 0, h2 = a.nk;
-    while (l2 < h2) { const long long mid = (l2 + h2) >> 1; if (a.Xk[mid] <= x_first) l2 = mid + 1; else h2 = mid; }
-    jj = l2 - 1;
-  }
-  while (p_lo < hi) {
-    // points of this interval: X < Xk[jj+1]
-    const long long p_hi = (jj + 1 < a.nk) ? min(hi, grid_lower_bound(a.g, a.nx, a.Xk[jj + 1])) : hi;
-    const long long j0 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj);
-    const long long j1 = jj < 0 ? 0 : (jj >= a.nk - 1 ? a.nk - 1 : jj + 1);
-    const double x0 = a.Xk[j0], dxk = a.Xk[j1] - a.Xk[j0];
-    float G0 = 0.f, G1 = 0.f;
-    for (long long i = p_lo + threadIdx.x; i < p_hi; i += blockDim.x) {
-      const double x = grid_x(a.g, a.g.offset + i);
-      const float w = ils_weight(a.kind, x, c, s);
-      const double x100 = x * 100.0;
-      const float B = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, a.c2l2e_over_T);
-      const float t = a.tau[i], ld = a.Ld[i];
-      const float f = dxk > 0.0 ? (float)((x - x0) / dxk) : 0.f;
-      const float gi = w * t * (B - ld);
-      Nsum += w;
-      Csum = fmaf(w, fmaf(t, ld, a.La[i]), Csum);
-      G1 = fmaf(gi, f, G1);
-      G0 = fmaf(gi, 1.0f - f, G0);
-    }
-    if (p_hi > p_lo) {
-      const float g0 = block_sum(G0, s_red), g1 = block_sum(G1, s_red);
-      if (threadIdx.x == 0) {  // one writer, intervals in ascending order: deterministic
-        Mrow[j0] += g0;
-        Mrow[j1] += g1;
-      }
-      jfirst = min(jfirst, (int)j0);
-      jlast = max(jlast, (int)j1);
-    }
-    p_lo = p_hi;
-    ++jj;
-  }
-  const float Nb = block_sum(Nsum, s_red), Cb = block_sum(Csum, s_red);
-  if (threadIdx.x == 0) {
-    a.N[b] = Nb;
-    a.C[b] = Cb;
-    a.jrange[b] = make_int2(jfirst == 0x7fffffff ? 0 : jfirst, jlast);
-  }
-}
-
+// rtx_band_moments does the monochromatic pass once (band_basis_moments_kernel in its PLANCK mode, further down: wavefront
+// reductions per knot interval, fixed order: deterministic); rtx_band_mix is the tiny [nB x nk] x [nk x nE] contraction
+// restricted to each band's knots.
 struct MixArgs {
   const float *N, *C, *M;
   const int2* jrange;
@@ -855,26 +758,6 @@ __global__ __launch_bounds__(256) void band_mix_kernel(MixArgs a) {
   float acc = a.C ? a.C[b] : 0.f;
   for (int j = jr.x; j <= jr.y; ++j) acc = fmaf(Mrow[j], a.E[(size_t)j * a.nE + k], acc);
   a.out[(size_t)b * a.nE + k] = a.N ? acc / a.N[b] : acc;  // N = 0 -> NaN, as the unfused path
-}
-
-extern "C" int rtx_band_moments(int kind, const rtx_grid* grid, const float* tau, const float* La, const float* Ld, double Ts,
-                                const double* Xk, int64_t nk, int nB, const double* centre, const double* sigma,
-                                float* N_out, float* C_out, float* M_out, int32_t* jrange_out, void* stream) {
-  if (kind != 0 && kind != 1) RTX_FAIL("kind must be 0 (triangle) or 1 (Gaussian)");
-  if (rtx_check_grid(grid)) return 1;
-  if (nk < 2) RTX_FAIL("need at least 2 knots");
-  if (nB < 0) RTX_FAIL("negative size");
-  if (nB == 0) return 0;
-  if (!(Ts > 0.0)) RTX_FAIL("surface temperature %g", Ts);
-  if (!tau || !La || !Ld || !Xk || !centre || !sigma || !N_out || !C_out || !M_out || !jrange_out) RTX_FAIL("a required pointer is NULL");
-  MomArgs a;
-  a.kind = kind; a.g = to_dev(grid); a.nx = grid->n; a.tau = tau; a.La = La; a.Ld = Ld;
-  a.c2l2e_over_T = 100.0 * RT_C2 * 1.4426950408889634 / Ts;
-  a.Xk = Xk; a.nk = nk; a.nB = nB; a.centre = centre; a.sigma = sigma;
-  a.N = N_out; a.C = C_out; a.M = M_out; a.jrange = reinterpret_cast<int2*>(jrange_out);
-  hipLaunchKernelGGL(band_moments_kernel, dim3(nB), dim3(256), 0, (hipStream_t)stream, a);
-  RTX_LAUNCH_CHECK();
-  return 0;
 }
 
 extern "C" int rtx_band_mix(const float* N, const float* C, const float* M, const int32_t* jrange, int nB, int64_t nk,
@@ -915,10 +798,11 @@ struct BasisArgs {
   const double* sigma;
   float coef[CUBE_QMAX][CUBE_QMAX];  // l_q(s) = sum_d coef[q][d] s^d
   float node_span;                   // R_b = node_span * sigma_b
+  double c2l2e_over_T;               // PLANCK mode (rtx_band_moments): 100*c2*log2(e)/Ts
   float* N;
   float* C;
-  float* MLd;  // [nB][nk]
-  float* MB;   // [Q][nB][nk]
+  float* MLd;  // [nB][nk]  (PLANCK mode: unused)
+  float* MB;   // [Q][nB][nk]  (PLANCK mode: M[nB][nk] = sum w tau (B(Ts) - Ld) hat_j)
   int2* jrange;
 };
 
@@ -966,9 +850,12 @@ __device__ __forceinline__ float wave_sum63(float v) {
   return v;
 }
 
-template <int KIND, int Q>
+// PLANCK (rtx_band_moments, config C4; Q = 1): the one row is M[b][j] = sum w tau (B(nu, Ts) - Ld) hat_j, no Ld row.
+template <int KIND, int Q, bool PLANCK>
 __global__ __launch_bounds__(64 * BBM_WAVES) void band_basis_moments_kernel(BasisArgs a) {
-  constexpr int NV = 2 * Q + 4, IG0 = 0, IG1 = Q, IL0 = 2 * Q, IL1 = 2 * Q + 1, IN = 2 * Q + 2, IC = 2 * Q + 3;
+  static_assert(!PLANCK || Q == 1, "PLANCK mode has one row");
+  constexpr int NROW = PLANCK ? 1 : Q + 1;  // rows of knot moments
+  constexpr int NV = 2 * NROW + 2, IG0 = 0, IG1 = Q, IL0 = 2 * Q, IL1 = 2 * Q + 1, IN = 2 * NROW, IC = 2 * NROW + 1;
   __shared__ float s_seg[BBM_SEGS][BBM_PARTS][BBM_NVMAX];
   __shared__ int s_j[BBM_SEGS][2];  // j0, j1 of the interval; j0 = -1: no points
   __shared__ double s_xk[BBM_SEGS + 1];
@@ -1039,7 +926,12 @@ __global__ __launch_bounds__(64 * BBM_WAVES) void band_basis_moments_kernel(Basi
       // x - c, f = (x - Xk[j0]) / dxk and the node abscissa as linear functions of the offset from the interval's first point
       const double x_ref = grid_x(a.g, a.g.offset + p_lo);
       const float d0 = (float)(x_ref - c), f00 = (float)((x_ref - x0) * inv_dxk_d), fstep = (float)(a.g.step * inv_dxk_d);
-      const bool linear = KIND == 0 && p_hi - p_lo < (1ll << 24);  // offsets exact in fp32
+      // PLANCK: the exponent nu * kT is linear too; its integer part is split off once per task (fp64), the fraction runs in fp32
+      const double t_ref = PLANCK ? x_ref * a.c2l2e_over_T : 0.0, n_ref = rint(t_ref);
+      const float tf_ref = (float)(t_ref - n_ref), tstep = (float)(a.g.step * a.c2l2e_over_T), x_ref_f = (float)x_ref;
+      const int n_ref_i = (int)n_ref;
+      // offsets exact in fp32; PLANCK: exponent >= 1.5 over the interval (else planck_f32's fp64 expm1 branch, point by point)
+      const bool linear = KIND == 0 && p_hi - p_lo < (1ll << 24) && (!PLANCK || (t_ref >= 1.6 && t_ref < 120.0));
       if (!(CUBE_ABLATE & 2))
       for (long long ib = p_lo + part * 64; ib < p_hi; ib += 64 * BBM_PARTS * BBM_UNROLL) {
         float tt[BBM_UNROLL], ll[BBM_UNROLL], aa[BBM_UNROLL];
@@ -1054,36 +946,51 @@ __global__ __launch_bounds__(64 * BBM_WAVES) void band_basis_moments_kernel(Basi
         for (int u = 0; u < BBM_UNROLL; ++u) {
           const long long i = ib + u * (64 * BBM_PARTS) + lane;
           const bool ok = i < p_hi;
-          float w, f, sn;
+          float w, f, sn, B = 0.f;
           if (linear) {
             const float uf = (float)(rel0 + u * (64 * BBM_PARTS));
             const float d = fmaf(uf, step_f, d0);
             w = fmaxf(fmaf(-fabsf(d), inv_s, 1.0f), 0.f);  // tri(), :1236-1239
             f = fmaf(uf, fstep, f00);
             sn = d * inv_Rn_f;
+            if (PLANCK) {
+              const float xf = fmaf(uf, step_f, x_ref_f);
+              const float e = ldexpf(__builtin_amdgcn_exp2f(fmaf(uf, tstep, tf_ref)), n_ref_i);
+              B = ((float)(RT_C1 * 1e10) * xf) * (xf * xf) * __builtin_amdgcn_rcpf(e - 1.0f);  // c1 (100 nu)^3 1e4 / (e - 1)
+            }
           } else {
             const double x = grid_x(a.g, a.g.offset + i);
             w = ils_weight(KIND, x, c, s);
             f = (float)((x - x0) * inv_dxk_d);
             sn = (float)((x - c) * inv_Rn);
+            if (PLANCK) {
+              const double x100 = x * 100.0;
+              B = planck_f32(RT_C1 * (x100 * x100 * x100) * 1e4, x, a.c2l2e_over_T);
+            }
           }
           w = ok ? w : 0.f;  // past the interval's end: the first point again, with weight 0
           const float t = tt[u], ld = ll[u];
           const float wt = w * t, f1 = 1.0f - f;
           v[IN] += w;
           v[IC] = fmaf(w, fmaf(t, ld, aa[u]), v[IC]);
+          if (PLANCK) {
+            const float gi = wt * (B - ld);
+            v[IG1] = fmaf(gi, f, v[IG1]);
+            v[IG0] = fmaf(gi, f1, v[IG0]);
+          } else {
 #pragma unroll
-          for (int q = 0; q < Q; ++q) {
-            float l = cv[q][Q - 1];
+            for (int q = 0; q < Q; ++q) {
+              float l = cv[q][Q - 1];
 #pragma unroll
-            for (int d = Q - 2; d >= 0; --d) l = fmaf(l, sn, cv[q][d]);
-            const float gq = wt * l;
-            v[IG1 + q] = fmaf(gq, f, v[IG1 + q]);
-            v[IG0 + q] = fmaf(gq, f1, v[IG0 + q]);
+              for (int d = Q - 2; d >= 0; --d) l = fmaf(l, sn, cv[q][d]);
+              const float gq = wt * l;
+              v[IG1 + q] = fmaf(gq, f, v[IG1 + q]);
+              v[IG0 + q] = fmaf(gq, f1, v[IG0 + q]);
+            }
+            const float gl = wt * ld;
+            v[IL1] = fmaf(gl, f, v[IL1]);
+            v[IL0] = fmaf(gl, f1, v[IL0]);
           }
-          const float gl = wt * ld;
-          v[IL1] = fmaf(gl, f, v[IL1]);
-          v[IL0] = fmaf(gl, f1, v[IL0]);
         }
       }
 #pragma unroll
@@ -1107,7 +1014,7 @@ __global__ __launch_bounds__(64 * BBM_WAVES) void band_basis_moments_kernel(Basi
     // knot j of this round collects, in interval order, the j0-sum of the intervals that start at it and the j1-sum of those
     // that end at it (the order one thread walking the intervals would add them in); one thread per (row, knot)
     if (CUBE_ABLATE & 4) {
-    } else if (threadIdx.x < (unsigned)((Q + 1) * (BBM_SEGS + 1))) {
+    } else if (threadIdx.x < (unsigned)(NROW * (BBM_SEGS + 1))) {
       const int qi = threadIdx.x / (BBM_SEGS + 1), jl = threadIdx.x % (BBM_SEGS + 1);
       const int i0 = qi == Q ? IL0 : IG0 + qi, i1 = qi == Q ? IL1 : IG1 + qi;  // rows 0..Q-1: the basis moments, row Q: Ld
       const long long j = jb + jl;
@@ -1137,7 +1044,7 @@ __global__ __launch_bounds__(64 * BBM_WAVES) void band_basis_moments_kernel(Basi
   // zeros on the knots the band does not reach
   for (long long j = threadIdx.x; j < a.nk; j += blockDim.x) {
     if (j >= w_lo && j <= w_hi) continue;
-    a.MLd[(size_t)b * a.nk + j] = 0.f;
+    if (!PLANCK) a.MLd[(size_t)b * a.nk + j] = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) a.MB[((size_t)q * a.nB + b) * a.nk + j] = 0.f;
   }
@@ -1157,13 +1064,38 @@ template <int KIND>
 static void launch_basis_moments(const BasisArgs& a, hipStream_t stream) {
   const dim3 grid(a.nB), block(64 * BBM_WAVES);
   switch (a.Q) {
-    case 1: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 1>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 2>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 3>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 4>), grid, block, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 5>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 6>), grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 1, false>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 2, false>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 3, false>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 4, false>), grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 5, false>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((band_basis_moments_kernel<KIND, 6, false>), grid, block, 0, stream, a); break;
   }
+}
+
+extern "C" int rtx_band_moments(int kind, const rtx_grid* grid, const float* tau, const float* La, const float* Ld, double Ts,
+                                const double* Xk, int64_t nk, int nB, const double* centre, const double* sigma,
+                                float* N_out, float* C_out, float* M_out, int32_t* jrange_out, void* stream) {
+  if (kind != 0 && kind != 1) RTX_FAIL("kind must be 0 (triangle) or 1 (Gaussian)");
+  if (rtx_check_grid(grid)) return 1;
+  if (nk < 2) RTX_FAIL("need at least 2 knots");
+  if (nB < 0) RTX_FAIL("negative size");
+  if (nB == 0) return 0;
+  if (!(Ts > 0.0)) RTX_FAIL("surface temperature %g", Ts);
+  if (!tau || !La || !Ld || !Xk || !centre || !sigma || !N_out || !C_out || !M_out || !jrange_out) RTX_FAIL("a required pointer is NULL");
+  // the C5 kernel in its PLANCK mode: one row, integrand w tau (B(nu, Ts) - Ld)
+  BasisArgs a;
+  a.kind = kind; a.Q = 1; a.g = to_dev(grid); a.nx = grid->n; a.tau = tau; a.La = La; a.Ld = Ld; a.Xk = Xk; a.nk = nk; a.nB = nB;
+  a.centre = centre; a.sigma = sigma; a.node_span = 1.0f;
+  for (int q = 0; q < CUBE_QMAX; ++q)
+    for (int d = 0; d < CUBE_QMAX; ++d) a.coef[q][d] = 0.f;
+  a.c2l2e_over_T = 100.0 * RT_C2 * 1.4426950408889634 / Ts;
+  a.N = N_out; a.C = C_out; a.MLd = nullptr; a.MB = M_out; a.jrange = reinterpret_cast<int2*>(jrange_out);
+  const dim3 g(nB), blk(64 * BBM_WAVES);
+  if (kind == 0) hipLaunchKernelGGL((band_basis_moments_kernel<0, 1, true>), g, blk, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((band_basis_moments_kernel<1, 1, true>), g, blk, 0, (hipStream_t)stream, a);
+  RTX_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int rtx_band_basis_moments(int kind, const rtx_grid* grid, const float* tau, const float* La, const float* Ld,
@@ -1181,7 +1113,7 @@ extern "C" int rtx_band_basis_moments(int kind, const rtx_grid* grid, const floa
     RTX_FAIL("a required pointer is NULL");
   BasisArgs a;
   a.kind = kind; a.Q = Q; a.g = to_dev(grid); a.nx = grid->n; a.tau = tau; a.La = La; a.Ld = Ld; a.Xk = Xk; a.nk = nk; a.nB = nB;
-  a.centre = centre; a.sigma = sigma; a.node_span = (float)node_span;
+  a.centre = centre; a.sigma = sigma; a.node_span = (float)node_span; a.c2l2e_over_T = 0.0;
   for (int q = 0; q < CUBE_QMAX; ++q)
     for (int d = 0; d < CUBE_QMAX; ++d) a.coef[q][d] = (q < Q && d < Q) ? basis_coef_h[q * Q + d] : 0.f;
   a.N = N_out; a.C = C_out; a.MLd = MLd_out; a.MB = MB_out; a.jrange = reinterpret_cast<int2*>(jrange_out);

@@ -39,22 +39,44 @@ def mako_bands(x_min, x_max, resFactor=None, fwhm_sf=1.0, shift=0.0, scale=1.0):
     return X_out, scale * X_out + shift, sigma
 
 
+_CUBE_PLANS = {}  # spectra-independent set-up of hsi_cube (band list, knots and node tables on the device), a few entries
+_CUBE_PLANS_MAX = 8
+_CUBE_PLANS_LOCK = threading.Lock()
+_FUSED_PLANS = {}  # band list and knot axis of band_radiance_fused on the device (a few entries, see _cube_plan)
+
+
+def _fused_plan(grid, Xk, resFactor, kind, dev):
+    Xk = np.ascontiguousarray(Xk, dtype=np.float64)
+    key = (grid.x_at(0), grid.step, grid.n, resFactor, int(kind), str(dev), Xk.tobytes())
+    with _CUBE_PLANS_LOCK:
+        plan = _FUSED_PLANS.get(key)
+    if plan is None:
+        if kind == 0:
+            X_out, centre, sigma = mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
+        else:  # Gaussian variant: no clipping, sigma = |gradient| (ILS_MAKO.py:19-21)
+            X_out = np.sort(10000.0 / _MAKO_UM)
+            centre, sigma = X_out, np.abs(np.gradient(X_out))
+        plan = {"X_out": np.array(X_out, dtype=np.float64), "Xk_d": torch.as_tensor(Xk, device=dev),
+                "c_d": torch.as_tensor(np.ascontiguousarray(centre, dtype=np.float64), device=dev),
+                "s_d": torch.as_tensor(np.ascontiguousarray(sigma, dtype=np.float64), device=dev)}
+        with _CUBE_PLANS_LOCK:
+            if len(_FUSED_PLANS) >= _CUBE_PLANS_MAX:
+                _FUSED_PLANS.pop(next(iter(_FUSED_PLANS)))
+            _FUSED_PLANS[key] = plan
+    return plan
+
+
 def band_radiance_fused(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, kind=0):
     """Same result as band_radiance() without any [nX][nE] array: one monochromatic pass
     (rtx_band_moments) + a [nB x nk] x [nk x nE] contraction over each band's ~10-30 knots (rtx_band_mix).
     Returns (X_out [nB] NumPy, L [nB][nE] float32 device)."""
     lib = _lib.load()
     dev = tau.device
-    if kind == 0:
-        X_out, centre, sigma = mako_bands(grid.x_at(0), grid.x_at(grid.n - 1), resFactor)
-    else:  # Gaussian variant: no clipping, sigma = |gradient| (ILS_MAKO.py:19-21)
-        X_out = np.sort(10000.0 / _MAKO_UM)
-        centre, sigma = X_out, np.abs(np.gradient(X_out))
+    plan = _fused_plan(grid, Xk, resFactor, kind, dev)
+    X_out = plan["X_out"].copy()
     nB, nk, nE = X_out.size, len(Xk), emis_knots.shape[1]
     assert emis_knots.dtype == torch.float32 and emis_knots.shape[0] == nk
     emis_knots = emis_knots.contiguous()
-    Xk_d = torch.as_tensor(np.asarray(Xk, dtype=np.float64), device=dev)
-    c_d, s_d = torch.as_tensor(centre, device=dev), torch.as_tensor(sigma, device=dev)
     N = torch.empty(nB, dtype=torch.float32, device=dev)
     Cb = torch.empty(nB, dtype=torch.float32, device=dev)
     M = torch.empty((nB, nk), dtype=torch.float32, device=dev)
@@ -62,8 +84,8 @@ def band_radiance_fused(grid, tau, La, Ld, Xk, emis_knots, Ts, resFactor=None, k
     out = torch.empty((nB, nE), dtype=torch.float32, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.rtx_band_moments(int(kind), grid.byref(), p(tau), p(La), p(Ld), float(Ts), p(Xk_d), nk, nB, p(c_d), p(s_d),
-                                    p(N), p(Cb), p(M), p(jr), st))
+    _lib.check(lib.rtx_band_moments(int(kind), grid.byref(), p(tau), p(La), p(Ld), float(Ts), p(plan["Xk_d"]), nk, nB, p(plan["c_d"]),
+                                    p(plan["s_d"]), p(N), p(Cb), p(M), p(jr), st))
     _lib.check(lib.rtx_band_mix(p(N), p(Cb), p(M), p(jr), nB, nk, p(emis_knots), nE, p(out), st))
     return X_out, out
 
@@ -79,9 +101,6 @@ def chebyshev_lagrange(Q):
     return s, coef
 
 
-_CUBE_PLANS = {}  # spectra-independent set-up of hsi_cube (band list, knots and node tables on the device), a few entries
-_CUBE_PLANS_MAX = 8
-_CUBE_PLANS_LOCK = threading.Lock()
 
 
 def _cube_plan(grid, Xk, resFactor, band_slice, Q, bands, dev):

@@ -1697,3 +1697,28 @@ def test_c5_cube_kernel_paths_vs_oracle(rt):
         xr, Lr = ref.ILS_MAKO(X, L, resFactor=2)
         assert np.array_equal(xo, xr) and cube.shape == Lr.shape, cs
         assert rel_err(cube.cpu().numpy(), Lr) <= TOL_L, cs
+
+
+def test_fused_band_radiance_gaussian_and_cold_vs_oracle(rt):
+    """sensor.band_radiance_fused (rtx_band_moments + rtx_band_mix) on the two paths the triangle / LWIR cases do not take:
+    the Gaussian band shapes (ILS_MAKO.py:2-35; every point evaluated in fp64) and a surface so hot that a MAKO band's Planck
+    exponent drops below 1.5 (planck_f32's expm1 branch instead of the per-task linear exponent)."""
+    import torch
+    from radtxfr_amd import engine, sensor
+    rng = np.random.default_rng(20261102)
+    dev = torch.device("cuda")
+    f32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32), device=dev)
+    grid = engine.Grid(745.0, 1335.0, 30000)
+    X = grid.axis()
+    tau = 0.5 + 0.45 * np.sin(X / 17.0)
+    La = 2.0 + np.cos(X / 31.0)
+    Ld = 4.0 + 2.0 * np.sin(X / 5.0)
+    Xk = np.sort(rng.uniform(740.0, 1340.0, 90))
+    em = rng.uniform(0.05, 1.0, (90, 4))
+    em_hi = np.stack([np.interp(X, Xk, em[:, k]) for k in range(4)], axis=1)
+    for Ts, kind in ((295.0, 1), (1400.0, 0), (1400.0, 1)):
+        L_ref = ref.compute_LWIR_apparent_radiance(X, em_hi, np.array([Ts]), tau[:, None], La[:, None], Ld[:, None])[:, :, 0]
+        xr, Lb_ref = ref.ILS_MAKO_gauss(X, L_ref) if kind else ref.ILS_MAKO(X, L_ref)
+        xf, Lf = sensor.band_radiance_fused(grid, f32(tau), f32(La), f32(Ld), Xk, f32(em), Ts, kind=kind)
+        assert np.array_equal(xf, xr), (Ts, kind)
+        assert rel_err(Lf.cpu().numpy(), Lb_ref) <= TOL_L, (Ts, kind)
