@@ -50,6 +50,14 @@ struct rtx_comm {
   NcclApi nccl;
   std::vector<nccl_comm_t> comms;
   std::vector<hipEvent_t> ready;  // per rank: its send block is complete (peer backend)
+  std::vector<hipEvent_t> done;   // per rank: it has pulled every peer's block (peer backend)
+};
+
+// puts the calling thread's current device back on every way out of a function that walks the devices
+struct DeviceRestore {
+  int dev = -1;
+  DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
 
 extern "C" int rtx_comm_destroy(rtx_comm* c) {
@@ -60,6 +68,7 @@ extern "C" int rtx_comm_destroy(rtx_comm* c) {
     (void)hipSetDevice(c->devs[i]);
     if (c->backend == 1 && i < (int)c->comms.size() && c->comms[i]) c->nccl.CommDestroy(c->comms[i]);
     if (i < (int)c->ready.size() && c->ready[i]) (void)hipEventDestroy(c->ready[i]);
+    if (i < (int)c->done.size() && c->done[i]) (void)hipEventDestroy(c->done[i]);
   }
   (void)hipSetDevice(cur);
   delete c;
@@ -84,13 +93,13 @@ extern "C" int rtx_comm_init_all(int ndev, const int* devs_h, int backend, rtx_c
     if (!strcmp(e, "peer")) backend = 0;
     if (!strcmp(e, "rccl")) backend = 1;
   }
+  DeviceRestore restore;
+  const int cur = restore.dev;
   rtx_comm* c = new rtx_comm();
   c->ndev = ndev;
   c->devs.assign(devs_h, devs_h + ndev);
   c->backend = 0;
   memset(&c->nccl, 0, sizeof(c->nccl));
-  int cur = 0;
-  RTX_HIP(hipGetDevice(&cur));
   if (backend != 0) {
     if (!distinct) {
       if (backend == 1) { delete c; RTX_FAIL("RCCL needs distinct devices (a device may repeat only with the peer-copy backend)"); }
@@ -106,17 +115,18 @@ extern "C" int rtx_comm_init_all(int ndev, const int* devs_h, int backend, rtx_c
     } else if (backend == 1) { delete c; RTX_FAIL("librccl.so could not be loaded: %s", dlerror()); }
   }
   c->ready.assign(ndev, nullptr);
+  c->done.assign(ndev, nullptr);
   for (int i = 0; i < ndev; ++i) {
     hipError_t e = hipSetDevice(c->devs[i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
       rtx_set_error("event on device %d: %s", c->devs[i], hipGetErrorString(e));
-      (void)hipSetDevice(cur);
+      if (cur >= 0) (void)hipSetDevice(cur);
       rtx_comm_destroy(c);
       return 1;
     }
   }
-  RTX_HIP(hipSetDevice(cur));
   *out = c;
   return 0;
 }
@@ -129,16 +139,17 @@ extern "C" int rtx_allgather(rtx_comm* c, const void* const* sendbufs_h, void* c
   if (!c || !sendbufs_h || !recvbufs_h || !streams_h) RTX_FAIL("a required pointer is NULL");
   if (count < 0) RTX_FAIL("count=%lld", (long long)count);
   if (count == 0) return 0;
-  int cur = 0;
-  RTX_HIP(hipGetDevice(&cur));
+  DeviceRestore restore;
   if (c->backend == 1) {
     int rc = c->nccl.GroupStart();
-    for (int i = 0; i < c->ndev && rc == 0; ++i) {
-      RTX_HIP(hipSetDevice(c->devs[i]));
-      rc = c->nccl.AllGather(sendbufs_h[i], recvbufs_h[i], (size_t)count, 7 /* ncclFloat32 */, c->comms[i], (hipStream_t)streams_h[i]);
+    hipError_t he = hipSuccess;
+    for (int i = 0; i < c->ndev && rc == 0 && he == hipSuccess; ++i) {
+      he = hipSetDevice(c->devs[i]);
+      if (he == hipSuccess)
+        rc = c->nccl.AllGather(sendbufs_h[i], recvbufs_h[i], (size_t)count, 7 /* ncclFloat32 */, c->comms[i], (hipStream_t)streams_h[i]);
     }
-    const int rc2 = c->nccl.GroupEnd();
-    RTX_HIP(hipSetDevice(cur));
+    const int rc2 = c->nccl.GroupEnd();  // the group is closed on every path
+    if (he != hipSuccess) RTX_FAIL("hipSetDevice: %s", hipGetErrorString(he));
     if (rc != 0 || rc2 != 0) RTX_FAIL("ncclAllGather failed: %s", c->nccl.GetErrorString ? c->nccl.GetErrorString(rc ? rc : rc2) : "?");
     return 0;
   }
@@ -156,7 +167,14 @@ extern "C" int rtx_allgather(rtx_comm* c, const void* const* sendbufs_h, void* c
       if ((const void*)dst == sendbufs_h[i]) continue;  // in place
       RTX_HIP(hipMemcpyPeerAsync(dst, c->devs[j], sendbufs_h[i], c->devs[i], bytes, st));
     }
+    RTX_HIP(hipEventRecord(c->done[j], st));
   }
-  RTX_HIP(hipSetDevice(cur));
+  // a rank's later work on its stream (the next step's kernels write its send block again) waits until every peer has
+  // read that block: as with a collective, the call is complete in a stream's order only when all ranks are through it
+  for (int i = 0; i < c->ndev; ++i) {
+    hipStream_t st = (hipStream_t)streams_h[i];
+    for (int j = 0; j < c->ndev; ++j)
+      if (j != i) RTX_HIP(hipStreamWaitEvent(st, c->done[j], 0));
+  }
   return 0;
 }
