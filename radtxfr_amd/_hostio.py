@@ -73,7 +73,13 @@ def _pinned_block(shape):
             _owned[0] -= t.numel() * 8
         _owned[0] += nbytes
         _lent[0] += nbytes
-    return torch.empty(shape, dtype=torch.float64, pin_memory=True)
+    try:
+        return torch.empty(shape, dtype=torch.float64, pin_memory=True)
+    except Exception:  # page-locking failed: the bytes were never owned
+        with _lent_lock:
+            _owned[0] -= nbytes
+            _lent[0] -= nbytes
+        raise
 
 
 def lend_block(shape):
