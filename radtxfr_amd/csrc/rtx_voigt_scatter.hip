@@ -35,6 +35,7 @@
 #include "rtx_voigt_math.h"
 
 #include "cheb8_64.inc"
+#include "cheb16_tile.inc"
 #include <vector>
 
 #ifndef RTX_SC_ABLATE
@@ -423,6 +424,10 @@ __global__ __launch_bounds__(256) void voigt_scatter_kernel(ScArgs a) {
 #ifndef SC_EDGE_UNROLL
 #define SC_EDGE_UNROLL 2
 #endif
+#ifndef RTX_SC_TILE_LEVEL
+#define RTX_SC_TILE_LEVEL 1  // full members >= RTX_SC_TILE_DIST points outside a 16-row tile: 16 tile nodes instead of 16 x 8 row nodes
+#endif
+#define RTX_SC_TILE_DIST 512
 #ifndef SC_ENT_CAP
 #define SC_ENT_CAP (SC_EDGE_LIST ? 16 : 32)  // point-by-point entries per wave (64 B each). Without the edge list, two waves per workgroup: 16 -> 2.02 ms, 24 -> 1.99, 32 -> 1.96, 48 -> 2.03
 #endif
@@ -440,7 +445,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
   __shared__ float4 s_edge[SC_NW][SC_EDGE_LIST ? SC_EDGE_CAP : 1][2];
   __shared__ float s_nodsum[RTX_SC_ROWS][CHEB_N];
   // after the last drain the entry lists are dead: wave w keeps its row-level sums [ROWS][8] in its list
-  static_assert(RTX_SC_ROWS * CHEB_N * 4 <= SC_ENT_CAP * 64, "row sums fit in one wave's entry list");
+  static_assert((RTX_SC_ROWS * CHEB_N + TCHEB_N + 1) * 4 <= SC_ENT_CAP * 64, "row sums + tile sums fit in one wave's entry list");
 
   const int tile = part_out ? b_or_tile : xcd_tile(b_or_tile);  // XCD-aware order (rtx_common.h)
   if (tile >= a.n_tiles) return;
@@ -464,13 +469,31 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
 
   // node evaluations: lane = (member l of the group, node j)
   const int l = lane >> 3, j = lane & 7;
-  const float off_j = CHEB_OFF[j];
   float nod[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) nod[r] = 0.f;
+  // tile level: lane (l, j) holds the tile nodes j and 15 - j of member slot l
+  constexpr bool TILE_LEVEL = RTX_SC_TILE_LEVEL && ROWS == 16;
+#ifndef RTX_SC_OFF_LDS
+#define RTX_SC_OFF_LDS 0
+#endif
+#if !RTX_SC_OFF_LDS
+  const float off_j = CHEB_OFF[j];
+#endif
+  // the lanes' node offsets live in LDS, a copy per wave read back by the same wave once per round (s_nodsum is free until the
+  // final stage): the kernel sits at its 80-register budget (6 waves per SIMD), and these two would be held for its whole length
+  if (lane < 8) {
+    s_nodsum[wave][lane] = CHEB_OFF[lane];
+    if (TILE_LEVEL) s_nodsum[SC_NW + wave][lane] = TCHEB_OFF[lane];
+  }
+  float tnod_a = 0.f, tnod_b = 0.f;
+  int n_tile_members = 0;  // wave-uniform
   int n_ent = 0;  // wave-uniform
   float4(*__restrict__ ent)[4] = s_ent[wave];
-  const unsigned long long lt = (1ull << lane) - 1ull;
+  // number of set bits of a wave mask below this lane: v_mbcnt_lo/hi on the (scalar) mask -- no per-lane mask registers
+  auto below = [](unsigned long long m) -> int {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  };
   auto pull = [](int src_lane, float v) -> float {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
   };
@@ -604,7 +627,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
       unsigned long long eb = __ballot(emit);
       while (eb) {
         const int room = SC_EDGE_CAP - n_edge;
-        const int r = __popcll(eb & lt);
+        const int r = below(eb);
         if (emit && r < room) {
           float4* d = edg[n_edge + r];
           d[0] = f0;
@@ -622,7 +645,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
       unsigned long long eb = __ballot(emit);
       while (eb) {
         const int room = SC_ENT_CAP - n_ent;
-        const int r = __popcll(eb & lt);
+        const int r = below(eb);
         if (emit && r < room) {
           float4* d = ent[n_ent + r];
           d[0] = f0;
@@ -639,15 +662,46 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
     }
     STAMP(1);  // entry emission
     // ---- row level, 8 member lines per pass; x of node j in row r = x0 + r dx (one FMA per row) ----------------
+    // Tile level: a full member whose centre lies >= RTX_SC_TILE_DIST points outside the tile is smooth over the WHOLE tile --
+    // its 16 rows x 8 nodes are replaced by the tile's 16 Chebyshev nodes (two per lane), carried to the row nodes once per
+    // tile by TCHEB_M in the final stage (interpolation error <= 4.1e-8 of the line's own contribution, tests/test_host.py;
+    // the classification is a function of the line and the tile alone: no dependence on shards or table subsets).
+    bool is_t = false;
+    if (TILE_LEVEL) {
+      is_t = m_far == ALL_ROWS && (ia - qi0 >= RTX_SC_TILE_DIST || qi0 - (ia + TILE - 1) >= RTX_SC_TILE_DIST);
+      const unsigned long long tb = __ballot(is_t);
+      if (tb) {
+        const int nT = __popcll(tb);
+        n_tile_members += nT;
+        const float toff_a = s_nodsum[SC_NW + wave][j];
+        const int src = __builtin_amdgcn_ds_permute((is_t ? below(tb) : 63) << 2, lane);
+        for (int g0 = 0; g0 < nT; g0 += 8) {
+          const int e = g0 + l;
+          const int sl = __builtin_amdgcn_ds_bpermute(e << 2, src);
+          const float qa = pull(sl, f0.x), qc = pull(sl, f0.y), qb1 = pull(sl, f0.z), qb0 = pull(sl, f0.w);
+          float qAy = pull(sl, f1.x), qAy0 = pull(sl, f1.y);
+          const float qub = pull(sl, ub);
+          if (e >= nT) { qAy = 0.f; qAy0 = 0.f; }  // empty slot of the last group
+          const float xa = fmaf(qub, qa, fmaf(toff_a, qa, qc));
+          const float xb = fmaf(qub, qa, fmaf(1023.0f - toff_a, qa, qc));
+          const float xxa = xa * xa, xxb = xb * xb;
+          tnod_a = fmaf(fmaf(xxa, qAy, qAy0), __builtin_amdgcn_rcpf(fmaf(xxa + qb1, xxa, qb0)), tnod_a);
+          tnod_b = fmaf(fmaf(xxb, qAy, qAy0), __builtin_amdgcn_rcpf(fmaf(xxb + qb1, xxb, qb0)), tnod_b);
+        }
+      }
+    }
     // full members first (no masks), then the partial ones
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const bool is_m = pass == 0 ? (m_far == ALL_ROWS) : (m_far != 0u && m_far != ALL_ROWS);
+      const bool is_m = pass == 0 ? (m_far == ALL_ROWS && !is_t) : (m_far != 0u && m_far != ALL_ROWS);
       const unsigned long long rb = __ballot(is_m);
       if (!rb) continue;
       const int nR = __popcll(rb);
+#if RTX_SC_OFF_LDS
+      const float off_j = s_nodsum[wave][j];
+#endif
       // member of rank r sends its lane id to lane r; the others all write to lane 63, which no member targets
-      const int src = __builtin_amdgcn_ds_permute((is_m ? __popcll(rb & lt) : 63) << 2, lane);
+      const int src = __builtin_amdgcn_ds_permute((is_m ? below(rb) : 63) << 2, lane);
       for (int g0 = 0; g0 < nR; g0 += 8) {
         const int e = g0 + l;
         const int sl = __builtin_amdgcn_ds_bpermute(e << 2, src);
@@ -683,6 +737,8 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
             num = __int_as_float(__float_as_int(num) & mb);                                \
             nod[r_ < ROWS ? r_ : 0] = fmaf(num, rden, nod[r_ < ROWS ? r_ : 0]);            \
           }
+          // (skipping the blocks of four rows that no member of the group has set -- a partial member has ~9 of its 16 rows set --
+          // behind a ballot each: 1.815 against 1.823 ms, not worth the branches)
           SC_PART_ROW(0) SC_PART_ROW(1) SC_PART_ROW(2) SC_PART_ROW(3) SC_PART_ROW(4) SC_PART_ROW(5) SC_PART_ROW(6) SC_PART_ROW(7)
           SC_PART_ROW(8) SC_PART_ROW(9) SC_PART_ROW(10) SC_PART_ROW(11) SC_PART_ROW(12) SC_PART_ROW(13) SC_PART_ROW(14) SC_PART_ROW(15)
           SC_PART_ROW(16) SC_PART_ROW(17) SC_PART_ROW(18) SC_PART_ROW(19) SC_PART_ROW(20) SC_PART_ROW(21) SC_PART_ROW(22) SC_PART_ROW(23)
@@ -705,6 +761,15 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
     v += __shfl_xor(v, 32);
     if (lane < 8) reinterpret_cast<float*>(&s_ent[wave][0][0])[r * CHEB_N + lane] = v;
   }
+  if (TILE_LEVEL) {  // the wave's 16 tile-node sums and its member count, behind its row sums
+    float va = tnod_a, vb = tnod_b;
+    va += __shfl_xor(va, 8);  vb += __shfl_xor(vb, 8);
+    va += __shfl_xor(va, 16); vb += __shfl_xor(vb, 16);
+    va += __shfl_xor(va, 32); vb += __shfl_xor(vb, 32);
+    float* ts = reinterpret_cast<float*>(&s_ent[wave][0][0]) + ROWS * CHEB_N;
+    if (lane < 8) { ts[lane] = va; ts[15 - lane] = vb; }
+    if (lane == 0) ts[16] = __int_as_float(n_tile_members);
+  }
   STAMP(2);
   __syncthreads();
   STAMP(6);  // barrier
@@ -714,6 +779,23 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
     float v = reinterpret_cast<const float*>(&s_ent[0][0][0])[o];
     if constexpr (SC_NW >= 2) v += reinterpret_cast<const float*>(&s_ent[1][0][0])[o];
     if constexpr (SC_NW == 4) v += reinterpret_cast<const float*>(&s_ent[2][0][0])[o] + reinterpret_cast<const float*>(&s_ent[3][0][0])[o];
+    if (TILE_LEVEL) {
+      int any = 0;
+#pragma unroll
+      for (int w = 0; w < SC_NW; ++w) any |= __float_as_int(reinterpret_cast<const float*>(&s_ent[w][0][0])[ROWS * CHEB_N + 16]);
+      if (any) {  // uniform over the workgroup
+        float c = 0.f;
+#pragma unroll
+        for (int t = 0; t < TCHEB_N; ++t) {
+          float tsum = reinterpret_cast<const float*>(&s_ent[0][0][0])[ROWS * CHEB_N + t];
+          if constexpr (SC_NW >= 2) tsum += reinterpret_cast<const float*>(&s_ent[1][0][0])[ROWS * CHEB_N + t];
+          if constexpr (SC_NW == 4)
+            tsum += reinterpret_cast<const float*>(&s_ent[2][0][0])[ROWS * CHEB_N + t] + reinterpret_cast<const float*>(&s_ent[3][0][0])[ROWS * CHEB_N + t];
+          c = fmaf(TCHEB_M[t][o], tsum, c);
+        }
+        v += c;
+      }
+    }
     s_nodsum[o >> 3][o & 7] = v;
   }
   __syncthreads();

@@ -290,6 +290,32 @@ def test_chebyshev_tables_match_generator_and_error_bounds():
             f = lambda t: 1.0 / ((t + d0) ** 2 + g * g)
             worst = max(worst, np.max(np.abs(W @ f(nodes) - f(p)) / f(p)))
     assert worst < 3e-7, worst
+    # tile level (round 3): cheb16_tile.inc is what the generator writes; 16 nodes over a 16-row tile keep a wing whose centre
+    # lies >= RTX_SC_TILE_DIST points outside the tile to 4.1e-8 of itself, ALSO after the carry to the 128 row nodes and
+    # the row-level interpolation from there (the path the kernel takes), in the fp32 node positions the kernel uses
+    inc16 = open(os.path.join(ROOT, "radtxfr_amd", "csrc", "cheb16_tile.inc")).read()
+    toff = np.array([float(v.rstrip("f")) for v in re.search(r"TCHEB_OFF\[8\] = \{([^}]*)\}", inc16).group(1).split(",")])
+    t = np.arange(16)
+    tn = 511.5 + 512.0 * np.cos((2 * t + 1) * np.pi / 32)
+    assert np.allclose(toff, tn[:8], rtol=1e-7)
+    tn32 = tn.astype(np.float32)
+    tn32[15 - np.arange(8)] = np.float32(1023.0) - tn32[:8]
+    tnu = tn32.astype(np.float64)
+    rows = re.findall(r"^  \{([^}]*)\},$", inc16[inc16.index("TCHEB_M"):], flags=re.M)
+    M = np.array([[float(v.rstrip("f")) for v in r.split(",")] for r in rows])  # [16 tile nodes][128 row nodes]
+    rownodes = (64.0 * np.arange(16)[:, None] + off[None, :]).ravel()
+    assert M.shape == (16, 128) and np.allclose(M, lagr(tnu, rownodes).T, atol=2e-7)
+    dist = int(re.search(r"#define RTX_SC_TILE_DIST (\d+)", src).group(1))
+    assert dist == 512
+    pt = np.arange(1024.0)
+    worst = 0.0
+    for g in (0.5, 10.0, 30.0, 100.0, 300.0):
+        for u0 in (-float(dist), -700.0, 1023.0 + dist, 1023.0 + 900.0):
+            f = lambda u: 1.0 / ((u - u0) ** 2 + g * g)
+            at_rownodes = (f(tnu) @ M).reshape(16, 8)          # carry: tile nodes -> row nodes
+            at_points = (W @ at_rownodes.T).T.ravel()          # row level: row nodes -> the 64 points of each row
+            worst = max(worst, np.max(np.abs(at_points - f(pt)) / f(pt)))
+    assert worst < 6e-8, worst
 
 
 def test_window_taps_reproduce_the_reference_smoother():
