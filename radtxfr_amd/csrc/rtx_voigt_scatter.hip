@@ -775,7 +775,7 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
   STAMP(6);  // barrier
   // stage 1: thread (r, jj) adds the waves' row-level sums in a fixed order
   static_assert(SC_NW == 1 || SC_NW == 2 || SC_NW == 4, "one, two or four waves per workgroup");
-  for (int o = threadIdx.x; o < ROWS * CHEB_N; o += 64 * SC_NW) {  // o = r * CHEB_N + jj
+  for (int o = wave * 64 + lane; o < ROWS * CHEB_N; o += 64 * SC_NW) {  // o = r * CHEB_N + jj (from the live lane id: no late use of threadIdx.x, which cost a spill)
     float v = reinterpret_cast<const float*>(&s_ent[0][0][0])[o];
     if constexpr (SC_NW >= 2) v += reinterpret_cast<const float*>(&s_ent[1][0][0])[o];
     if constexpr (SC_NW == 4) v += reinterpret_cast<const float*>(&s_ent[2][0][0])[o] + reinterpret_cast<const float*>(&s_ent[3][0][0])[o];
