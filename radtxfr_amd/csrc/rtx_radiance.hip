@@ -831,7 +831,7 @@ struct BasisArgs {
 // grid_lower_bound without the search: the index from the grid's arithmetic, then stepped until it is the first with X >= v
 __device__ __forceinline__ long long grid_lower_bound_direct(const GridDev& g, long long n, double v) {
   const double r = ceil((v - g.xmin) / g.step) - (double)g.offset;
-  long long i = r <= 0.0 ? 0 : (r >= (double)n ? n : (long long)r);  // NaN -> n
+  long long i = !(r > 0.0) ? 0 : (!(r < (double)n) ? n : (long long)r);  // NaN -> 0 (no conversion of a NaN)
   while (i > 0 && grid_x(g, g.offset + i - 1) >= v) --i;
   while (i < n && grid_x(g, g.offset + i) < v) ++i;
   return i;
