@@ -737,6 +737,9 @@ __device__ __forceinline__ void nodal_tile(const ScArgs& a, const int b_or_tile,
             num = __int_as_float(__float_as_int(num) & mb);                                \
             nod[r_ < ROWS ? r_ : 0] = fmaf(num, rden, nod[r_ < ROWS ? r_ : 0]);            \
           }
+          // (row-level members parked in an LDS list until eight are together -- every group full, two ds_read_b128 instead of
+          // a ds_permute and nine ds_bpermute per group -- 1.83 against 1.81 ms: the list's emission loop costs what the fuller
+          // groups save)
           // (skipping the blocks of four rows that no member of the group has set -- a partial member has ~9 of its 16 rows set --
           // behind a ballot each: 1.815 against 1.823 ms, not worth the branches)
           SC_PART_ROW(0) SC_PART_ROW(1) SC_PART_ROW(2) SC_PART_ROW(3) SC_PART_ROW(4) SC_PART_ROW(5) SC_PART_ROW(6) SC_PART_ROW(7)
