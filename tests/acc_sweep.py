@@ -1,5 +1,5 @@
 """Accuracy sweep at full C3 size: the 32-layer TUD on the whole 500-6000 cm^-1 grid, compared with the oracle on random
-1500-point windows (optical depth of every layer, tau, L-up, L-down). python tools/acc_sweep.py [--windows 6]"""
+1500-point windows (optical depth of every layer, tau, L-up, L-down). python tests/acc_sweep.py [--windows 6]"""
 import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

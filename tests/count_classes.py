@@ -2,7 +2,7 @@
 """CPU-side census of the line-sum's work on the C3 workload, with the nodal kernel's geometry (16-row tiles, near zone
 +- 2 rows): per tile and layer, how many candidate lines, how many reach the tile, how many are row-level members (full:
 every row of the tile a far row; partial), how many rows go point by point (near zone / window edge / Weideman band).
-Pure NumPy on the oracle's line parameters; no GPU.   python tools/count_classes.py"""
+Pure NumPy on the oracle's line parameters; no GPU.   python tests/count_classes.py"""
 import os
 import sys
 

@@ -617,7 +617,7 @@ def test_full_c3_stratified_windows_vs_oracle():
     points STRATIFIED over 500-6000 cm^-1 -- five of them inside the LWIR span 500-1500 cm^-1, the first and the last tile
     of the axis, a window across the middle tile boundary -- for the SURVEY-8d column (opaque almost everywhere) and the
     same column with mixing ratios x 1e-3 (tau spans (0, 1)): optical depth of all 32 layers, tau, L-up, L-down at the
-    standing tolerances. (tools/acc_sweep.py as a driver-run test.)"""
+    standing tolerances. (tests/acc_sweep.py as a driver-run test.)"""
     import torch
     from radtxfr_amd import engine
     full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
