@@ -270,8 +270,10 @@ int rtx_pixel_cube(int nB, int Q, const double* centre, const double* sigma, dou
  * absorptionCoefficient_SDVoigt, misc/hapi.py:10897-10900 (PROFILE_SDVOIGT :10117 -> pcqsdhc :9850-10024 with
  * anuVC = eta = 0: PART1 for lines without speed dependence, PART2/3/4 otherwise; CPF = hum1_wei :9833, cpf3 :9645),
  * after rtx_line_prep_profile(..., RTX_PROFILE_SDVOIGT, ...). Evaluated in fp64 (the profile is a difference of two
- * complex probability functions), one thread per grid point; this is the cross-section generator's path
- * (misc/RT_gen_AbsXS_files.py:90), not the TUD hot path.
+ * complex probability functions): a workgroup per tile of 1024 points, far wings at Chebyshev nodes (32 per tile / 12 per
+ * 64-point row, interpolation <= 1e-10 of a line's own contribution), the rows around a centre and around every regime
+ * switch point by point; RADTXFR_SD_KERNEL=gather selects the one-thread-per-point cross-check. This is the
+ * cross-section generator's path (misc/RT_gen_AbsXS_files.py:90), not the TUD hot path.
  *   out_f32[n_layers][ld] (may be NULL)  (float)(sum * scale);  out_f64[n_layers][ld] (may be NULL)  sum */
 int rtx_sdvoigt_sum(const rtx_prep* prep, const rtx_grid* grid, int n_layers, float* out_f32,
                     double* out_f64, int64_t ld, void* stream);

@@ -285,8 +285,8 @@ def absorptionCoefficient_SDVoigt(Components=None, SourceTables=None, partitionF
 
     Tables without speed-dependence columns (the 160-character HITRAN .par format has none) give Gamma2 = 0, for which
     pcqsdhc takes its PART1 branch (:9908-9915), i.e. the Voigt profile: those go through the fp32 Voigt line-sum.
-    Tables with non-zero SD_air / SD_self (:10884-10890) go through rtx_sdvoigt_sum: pcqsdhc PART2-4 in fp64, one thread
-    per grid point (the path of the reference's cross-section generator, misc/RT_gen_AbsXS_files.py:90)."""
+    Tables with non-zero SD_air / SD_self (:10884-10890) go through rtx_sdvoigt_sum: pcqsdhc PART2-4 in fp64, far wings at
+    Chebyshev nodes (the path of the reference's cross-section generator, misc/RT_gen_AbsXS_files.py:90)."""
     sd = False
     for name in listOfTuples(SourceTables):
         if name is None or name not in LOCAL_TABLE_CACHE:

@@ -812,6 +812,42 @@ def test_cross_sections_at_the_reference_callers_settings(hapi):
         hapi.LOCAL_TABLE_CACHE.pop(n)
 
 
+def test_sdvoigt_node_levels_equal_point_by_point(hapi):
+    """rtx_sdvoigt_sum's default kernel (far wings at 32 tile nodes / 12 row nodes in fp64, csrc/rtx_sdvoigt.hip) against its
+    point-by-point cross-check (RADTXFR_SD_KERNEL=gather) on a table that mixes every regime of pcqsdhc: SD = 0 (PART1), a
+    tiny speed dependence (PART2 over the whole window), ordinary values (PART4, closed-form far wing) and a large one
+    (Gamma0 close to 1.5 Gamma2), at the surface, at 0.01 atm and at 1e-4 atm, with wings of 350 and of 50
+    half-widths, on a grid whose last tile is ragged. The node levels may differ from the point-by-point sum by their
+    interpolation bound (1e-10 of each line's own positive contribution)."""
+    n = 3000
+    tbl = dict(synthetic.synth_line_table(91, n, 760.0, 1040.0))
+    rng = np.random.default_rng(92)
+    sd = np.round(rng.uniform(0.05, 0.2, n), 3)
+    kind = rng.integers(0, 8, n)
+    sd[kind == 0] = 0.0
+    sd[kind == 1] = 1e-9
+    sd[kind == 2] = 0.6
+    sd[kind == 3] = 1e-5
+    tbl["SD_air"] = sd
+    hapi.storage2cache_from_columns("sdmix", tbl)
+    X = np.linspace(800.0, 1000.0, 80001)
+    worst = 0.0
+    for T, p, hw in ((296.0, 1.0, 350.0), (230.0, 0.01, 350.0), (250.0, 1e-4, 350.0), (296.0, 0.5, 50.0)):
+        kw = dict(SourceTables="sdmix", Environment={"T": T, "p": p}, OmegaGrid=X, WavenumberWingHW=hw)
+        _, xs = hapi.absorptionCoefficient_SDVoigt(**kw)
+        os.environ["RADTXFR_SD_KERNEL"] = "gather"
+        try:
+            _, xg = hapi.absorptionCoefficient_SDVoigt(**kw)
+        finally:
+            del os.environ["RADTXFR_SD_KERNEL"]
+        nz = xg != 0.0
+        assert nz.any() and np.all(xg >= 0.0) and np.array_equal(xs[~nz], xg[~nz])
+        e = float(np.max(np.abs(xs[nz] - xg[nz]) / xg[nz]))
+        worst = max(worst, e)
+        assert e <= 1e-9, (T, p, hw, e)
+    hapi.LOCAL_TABLE_CACHE.pop("sdmix")
+
+
 def test_afit_xs_grid_batched_states(hapi, tmp_path):
     """afit_xs.cross_section_grid / generate_xs_files (the T x p loop of misc/RT_gen_AbsXS_files.py:86-92 as one
     batched launch): every state equals the per-state hapi shim call and agrees with the oracle; files round-trip."""
