@@ -15,9 +15,10 @@ import struct
 import numpy as np
 import torch
 
-from . import _lib, engine
+from . import _hostio, _lib, engine
 from . import hapi as _hapi
 
+_STAGE = {}  # one reusable pinned staging block for cross_section_grid (grow-only)
 _HEADER = struct.Struct("<2s6d128s")
 
 
@@ -87,7 +88,20 @@ def cross_section_grid(SourceTables, T, P_atm, X, WavenumberWingHW=50.0, Wavenum
                     per = max(1, per // 4)
                     continue
                 raise
-            out[s0:s0 + len(chunk)] = dev.cpu().numpy()
+            # device -> one reusable pinned block (a pageable hipMemcpy runs at a few GB/s) -> the result rows, widened by
+            # the host thread pool so that the fresh pages of `out` are faulted in parallel
+            need = len(chunk) * grid.n
+            pinned = _STAGE.get("buf")
+            if pinned is None or pinned.numel() < need:  # kept between calls: page-locking a block of this size costs ~70 ms
+                pinned = _STAGE["buf"] = torch.empty((need,), dtype=torch.float64, pin_memory=True)
+            pinned = pinned[:need].view(len(chunk), grid.n)
+            pinned[:len(chunk)].copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            src = pinned.numpy()
+            futs = [_hostio._threads().submit(np.copyto, out[s0 + r, c0:c0 + _hostio._CHUNK], src[r, c0:c0 + _hostio._CHUNK])
+                    for r in range(len(chunk)) for c0 in range(0, grid.n, _hostio._CHUNK)]
+            for f in futs:
+                f.result()
         else:
             out[s0:s0 + len(chunk)] = 0.0
         s0 += len(chunk)
