@@ -113,6 +113,7 @@ struct rtx_lines {
   double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
   double *sd_air, *sd_self;  // optional speed-dependence columns (rtx_lines_set_sd), NULL = 0
   double* deltap_self;       // optional (rtx_lines_set_deltap_self), NULL = 0
+  double* zn;                // per line: exp(-c2 E''/Tref) (1 - exp(-c2 nu/Tref)), the layer-independent half of S(T), formed once at creation
   int* species;
   // host side, for the bound on candidates per tile (hot-tile split, below): the sorted centres and column extremes
   double* nu_host;

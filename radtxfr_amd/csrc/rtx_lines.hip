@@ -55,7 +55,7 @@ static int upload(double** dst, const double* src_h, long long n, bool zero_if_n
 extern "C" int rtx_lines_free(rtx_lines* L) {
   if (!L) return 0;
   double* p[] = {L->nu, L->sw, L->elower, L->gamma_air, L->gamma_self, L->n_air, L->n_self, L->delta_air, L->deltap_air, L->delta_self,
-                 L->sd_air, L->sd_self, L->deltap_self};
+                 L->sd_air, L->sd_self, L->deltap_self, L->zn};
   for (double* q : p)
     if (q) (void)hipFree(q);
   if (L->species) (void)hipFree(L->species);
@@ -64,6 +64,7 @@ extern "C" int rtx_lines_free(rtx_lines* L) {
   return 0;
 }
 
+int rtx_lines_fill_zn(rtx_lines* L);
 extern "C" int rtx_lines_create(int64_t n, int n_species, const double* nu_h, const double* sw_h, const double* elower_h,
                                 const double* gamma_air_h, const double* gamma_self_h, const double* n_air_h,
                                 const double* n_self_h, const double* delta_air_h, const double* deltap_air_h,
@@ -101,6 +102,7 @@ extern "C" int rtx_lines_create(int64_t n, int n_species, const double* nu_h, co
       rc = 1;
     }
   }
+  if (!rc) rc = rtx_lines_fill_zn(L);
   if (!rc && n > 0) {
     L->nu_host = (double*)malloc(sizeof(double) * (size_t)n);
     if (!L->nu_host) { rtx_set_error("out of host memory"); rc = 1; }
@@ -207,9 +209,26 @@ extern "C" int rtx_prep_create(const rtx_lines* lines, int max_layers, int64_t m
 #endif
 #define RTX_ENV_MAX 416  /* doubles of per-layer tables carried in the prologue's kernel arguments (3.3 KB of the 4 KB) */
 
+// The reference-temperature half of S(T) (misc/hapi.py:10171-10172) depends on the line alone: formed once per table, by the
+// same expression the prologue used to evaluate per (line, layer) -- two of its four fp64 exponentials and two divisions.
+__global__ __launch_bounds__(256) void lines_zn_kernel(const double* __restrict__ nu, const double* __restrict__ elower, double* __restrict__ zn,
+                                                       long long n) {
+  const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < n) zn[l] = exp(-H_C2 * elower[l] / H_TREF) * (1.0 - exp(-H_C2 * nu[l] / H_TREF));
+}
+int rtx_lines_fill_zn(rtx_lines* L) {
+  if (L->n == 0) return 0;
+  RTX_HIP(hipMalloc((void**)&L->zn, sizeof(double) * (size_t)L->n));
+  hipLaunchKernelGGL(lines_zn_kernel, dim3((unsigned)((L->n + 255) / 256)), dim3(256), 0, 0, L->nu, L->elower, L->zn, (long long)L->n);
+  RTX_LAUNCH_CHECK();
+  RTX_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
 struct PrepArgs {
   const double *nu, *sw, *elower, *gamma_air, *gamma_self, *n_air, *n_self, *delta_air, *deltap_air, *delta_self;
   const double *sd_air, *sd_self, *deltap_self;
+  const double* zn;
   LineRecSD* recsd;
   const int* species;
   long long n_lines;
@@ -285,11 +304,14 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     // Gamma0 / Shift0 over the diluent mix, misc/hapi.py:11090-11128
     double Gamma0 = 0.0, Shift0 = 0.0;
     const double tr = H_TREF / T;
+    // (Tref/T)^n as exp(n log(Tref/T)): the logarithm is the same for every line of the layer; |n log(Tref/T)| < 1, so the
+    // result is within 2 ulp of pow's (whose extended-precision logarithm is 200 fp64 instructions of this kernel's ~1000)
+    const double ltr = log(tr);
     if (a.dil_air != 0.0) {
 #if RTX_PREP_ABLATE & 1  /* timing experiments only */
       Gamma0 += a.dil_air * (a.gamma_air[l] * p / 1.0 * (tr * a.n_air[l]));
 #else
-      Gamma0 += a.dil_air * (a.gamma_air[l] * p / 1.0 * pow(tr, a.n_air[l]));
+      Gamma0 += a.dil_air * (a.gamma_air[l] * p / 1.0 * exp(a.n_air[l] * ltr));
 #endif
       const double dp = a.deltap_air ? a.deltap_air[l] : 0.0;
       Shift0 += a.dil_air * ((a.delta_air[l] + dp * (T - H_TREF)) * p / 1.0);
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     if (a.dil_self != 0.0) {
       double ns = a.n_self ? a.n_self[l] : a.n_air[l];
       if (a.n_self && ns == 0.0) ns = a.n_air[l];
-      Gamma0 += a.dil_self * (a.gamma_self[l] * p / 1.0 * pow(tr, ns));
+      Gamma0 += a.dil_self * (a.gamma_self[l] * p / 1.0 * exp(ns * ltr));
       const double ds = a.delta_self ? a.delta_self[l] : 0.0;
       const double dps = a.deltap_self ? a.deltap_self[l] : 0.0;
       Shift0 += a.dil_self * ((ds + dps * (T - H_TREF)) * p / 1.0);
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(PrepArgs a) {
     const double zn = (-H_C2 * el / H_TREF) * (1.0 - (-H_C2 * nu / H_TREF));
 #else
     const double ch = exp(-H_C2 * el / T) * (1.0 - exp(-H_C2 * nu / T));
-    const double zn = exp(-H_C2 * el / H_TREF) * (1.0 - exp(-H_C2 * nu / H_TREF));
+    const double zn = a.zn[l];  // exp(-H_C2 * el / H_TREF) * (1.0 - exp(-H_C2 * nu / H_TREF)), from table creation (lines_zn_kernel)
 #endif
     const double S = a.sw[l] * eq[(size_t)sp * a.n_layers + k] * ch / zn;
     const bool dropped = pre_dropped || (S < a.thresh);
@@ -540,7 +562,7 @@ extern "C" int rtx_line_prep_profile(rtx_prep* P, const rtx_lines* L, const rtx_
   a.nu = L->nu; a.sw = L->sw; a.elower = L->elower; a.gamma_air = L->gamma_air; a.gamma_self = L->gamma_self;
   a.n_air = L->n_air; a.n_self = L->n_self; a.delta_air = L->delta_air; a.deltap_air = L->deltap_air;
   a.delta_self = L->delta_self; a.species = L->species;
-  a.sd_air = L->sd_air; a.sd_self = L->sd_self; a.deltap_self = L->deltap_self; a.recsd = P->recsd;
+  a.sd_air = L->sd_air; a.sd_self = L->sd_self; a.deltap_self = L->deltap_self; a.recsd = P->recsd; a.zn = L->zn;
   a.n_lines = L->n; a.n_layers = n_layers; a.n_species = ns;
   if (env_args) {  // offsets (in doubles) into a.env, carried in the pointer fields
     a.T = (const double*)(size_t)0; a.p = (const double*)nT; a.qratio = (const double*)(2 * nT);
