@@ -418,9 +418,9 @@ def main():
                        "pipelines_per_gpu": NP},
             "roofline": {"kernel": "voigt_nodal_kernel",
                          # the kernel moves 1.1x its algorithmic bytes and is nowhere near HBM speed: what binds it is
-                         # vector-instruction issue (SURVEY 8d stage A). The contract's HBM figures stay in
-                         # achieved/peak/frac; `valu` is the roofline it is actually up against.
-                         "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         # vector-instruction issue (SURVEY 8d stage A). `bound` names the roofline that achieved / peak /
+                         # frac are quoted against (the contract's HBM one); `binding_unit` + `valu` say what it is actually up against.
+                         "bound": "hbm", "binding_unit": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": tsrc if traffic is not None else None,
                          "ms_per_launch": ms_voigt, "algorithmic_bytes_per_launch": alg_bytes,
