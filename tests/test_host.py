@@ -517,3 +517,86 @@ def test_range_search_step_count():
             for v in rng.integers(-60, 3 * n + 60, 6).tolist() + [ic[0], ic[-1], ic[n // 2]]:
                 assert search(ic, v, True, steps) == bisect.bisect_left(ic, v)
                 assert search(ic, v, False, steps) == bisect.bisect_right(ic, v)
+
+
+def test_sdvoigt_regime_zones_and_node_error_bounds():
+    """The closed forms behind the speed-dependent Voigt kernel's node levels (csrc/rtx_sdvoigt.hip: sd_zones), restated in
+    NumPy. (1) pcqsdhc's PART4 takes hum1_wei's one-term asymptote for both arguments iff |x1| + y1 >= 15 with
+    Z1 = sqrt(X + Y) - csqrtY = y1 - i x1; with sqrt(X + Y) = p + iq that is p + |q| >= K = 15 + csqrtY, and
+    (p + |q|)^2 = |X + Y| + |Im X| gives |Im X| >= (K^4 - R^2) / (2 K^2), R = Re X + Y: the threshold is checked against the
+    pointwise test on both sides, over the physical range of the records. (2) The PART2 / PART3 thresholds are circles in X.
+    (3) Interpolating the far-wing closed form at 32 Chebyshev nodes over 1024 points (centre >= 256 points away) and at 12
+    nodes over 64 points (centre >= 3 rows away) keeps 1e-10 of the line's own contribution, the figures the kernel's header
+    quotes."""
+    rng = np.random.default_rng(17)
+
+    def far_threshold(gam0, gam2, cte):
+        a, c2 = gam0 - 1.5 * gam2, gam2
+        sY = 1.0 / (2.0 * cte * c2)
+        Y = sY * sY
+        K2 = (15.0 + sY) ** 2
+        R = a / c2 + Y
+        d = 225.0 + 30.0 * sY - a / c2
+        return c2 * (d * (K2 + R)) / (2.0 * K2) if d > 0 else 0.0
+
+    def is_far(gam0, gam2, cte, delta):
+        a, c2 = gam0 - 1.5 * gam2, gam2
+        sY = 1.0 / (2.0 * cte * c2)
+        X = complex(a, delta) / c2
+        Z1 = np.sqrt(X + sY * sY) - sY
+        return abs(Z1.imag) + Z1.real >= 15.0
+
+    n_checked = 0
+    for _ in range(400):
+        gam0 = 10.0 ** rng.uniform(-6, -0.5)
+        gam2 = gam0 * 10.0 ** rng.uniform(-6, -0.2) * 0.6
+        cte = np.sqrt(np.log(2.0)) / 10.0 ** rng.uniform(-4, -1.5)
+        t = far_threshold(gam0, gam2, cte)
+        if t <= 0.0:
+            assert is_far(gam0, gam2, cte, 0.0)
+            continue
+        # (probed at +-1e-6: for a tiny Gamma2 the pointwise test itself is only good to ~1e-8 of delta -- Z1 is the difference
+        # of two numbers of size csqrtY, and PART4 is only entered where |X| > 3e-8 Y, which bounds that noise by 1.3e-8 delta;
+        # the kernel keeps two grid points between a switch and the rows it takes to the node levels)
+        assert is_far(gam0, gam2, cte, t * (1 + 1e-6)) and not is_far(gam0, gam2, cte, t * (1 - 1e-6)), (gam0, gam2, cte, t)
+        n_checked += 1
+        # PART2: |X| <= 3e-8 Y  <=>  delta <= sqrt((3e-8 Y c2)^2 - a^2); PART3: |X| >= 1e15 Y likewise
+        a, c2 = gam0 - 1.5 * gam2, gam2
+        Y = (1.0 / (2.0 * cte * c2)) ** 2
+        for fac in (3.0e-8, 1.0e15):
+            tt = fac * Y * c2
+            if tt > a and np.isfinite(tt * tt):
+                dth = np.sqrt(tt * tt - a * a)
+                if dth > 1e-3 * a:  # (the square root loses the threshold's digits when it is a small difference)
+                    for s, want in ((1 + 1e-6, False), (1 - 1e-6, True)):
+                        assert (abs(complex(a, dth * s) / c2) <= fac * Y) == want
+    assert n_checked > 200
+
+    # (3) node levels on the far-wing closed form f(t1) - f(t2), t = Z, for a narrow line (singularities ~ on the real axis)
+    def far_profile(delta, gam0=0.07, gam2=0.009, cte=574.0):
+        a, c2 = gam0 - 1.5 * gam2, gam2
+        sY = 1.0 / (2.0 * cte * c2)
+        X = (a + 1j * delta) / c2
+        t1 = np.sqrt(X + sY * sY) - sY
+        t2 = t1 + 2.0 * sY
+        return (cte * (-2.0 * sY) * (0.5 - t1 * t2) / ((0.5 + t1 * t1) * (0.5 + t2 * t2))).real
+
+    def cheb_err(n_nodes, L, dist, step):
+        h = (L - 1) / 2.0
+        xj = h + h * np.cos((2 * np.arange(n_nodes) + 1) * np.pi / (2 * n_nodes))
+        p = np.arange(L, dtype=np.float64)
+        fj = far_profile((xj + dist) * step)
+        w = np.ones((n_nodes, L))
+        for j in range(n_nodes):
+            for m in range(n_nodes):
+                if m != j:
+                    w[j] *= (p - xj[m]) / (xj[j] - xj[m])
+        want = far_profile((p + dist) * step)
+        return float(np.max(np.abs(fj @ w - want) / want))
+
+    step = 0.0025
+    # the far regime of this line starts ~400 points from its centre; tile level from max(256 points, that)
+    assert cheb_err(32, 1024, 420.0, step) <= 1e-10
+    assert cheb_err(32, 1024, 256.0, 0.05) <= 1e-10   # coarse grid: the regime boundary lies inside 256 points
+    assert cheb_err(12, 64, 420.0, step) <= 1e-10
+    assert cheb_err(12, 64, 129.0, 0.05) <= 1e-10     # three rows from the centre row at the least: >= 129 points to the centre
