@@ -17,7 +17,7 @@ cd /tmp
 # a second trace of the default command (two pipelines: kernels of two atmospheres share the chip) is kept beside it
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline --pipelines 1 > "$OUT/bench_prof.json" 2> "$OUT/trace.err" || exit 2
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pipelined" -o run -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline > "$OUT/bench_prof_pipelined.json" 2> "$OUT/trace_pipelined.err" || exit 2
-for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES" "busy:SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" "trans:SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES" "busy:SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE" "trans:SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "stall:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$name" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --pipelines 1 > /dev/null 2> "$OUT/pmc_$name.err" || exit 3
 done
