@@ -845,6 +845,24 @@ def test_sdvoigt_node_levels_equal_point_by_point(hapi):
         e = float(np.max(np.abs(xs[nz] - xg[nz]) / xg[nz]))
         worst = max(worst, e)
         assert e <= 1e-9, (T, p, hw, e)
+    # ragged and tiny grids, and a wavenumber shard with an offset (engine API): one point, one row + 1, one tile + 1
+    import torch
+    from radtxfr_amd import engine
+    lines = hapi._device_table(["sdmix"])
+    w = np.ones((len(lines.species), 1))
+    for n_tot, off, cnt in ((2, 0, 2), (2, 1, 1), (65, 0, 65), (40001, 0, 1025), (40001, 30000, 5000), (40001, 39999, 2)):
+        grid = engine.Grid(900.0, 1000.0, n_tot).shard(off, cnt)
+        outs = []
+        for kern in ("", "gather"):
+            if kern:
+                os.environ["RADTXFR_SD_KERNEL"] = kern
+            try:
+                o = torch.empty((1, cnt), dtype=torch.float64, device="cuda")
+                engine.voigt_sum(lines, grid, [296.0], [1.0], w, out_f64=o, omega_wing_hw=350.0, scale=2.0 ** 70, profile=3)
+                outs.append(o.cpu().numpy()[0])
+            finally:
+                os.environ.pop("RADTXFR_SD_KERNEL", None)
+        assert np.all(outs[1] > 0.0) and float(np.max(np.abs(outs[0] - outs[1]) / outs[1])) <= 1e-9, (n_tot, off, cnt)
     hapi.LOCAL_TABLE_CACHE.pop("sdmix")
 
 
