@@ -18,6 +18,12 @@ import torch
 from . import _hostio, _lib, engine
 from . import hapi as _hapi
 
+def _touch_pages(a):
+    """Write one element per 4 KiB page of a fresh float64 slice (the values are overwritten by the copy that follows)."""
+    a[::512] = 0.0
+    a[-1:] = 0.0
+
+
 _STAGE = {}  # one reusable pinned staging block for cross_section_grid (grow-only)
 _HEADER = struct.Struct("<2s6d128s")
 
@@ -88,8 +94,13 @@ def cross_section_grid(SourceTables, T, P_atm, X, WavenumberWingHW=50.0, Wavenum
                     per = max(1, per // 4)
                     continue
                 raise
-            # device -> one reusable pinned block (a pageable hipMemcpy runs at a few GB/s) -> the result rows, widened by
-            # the host thread pool so that the fresh pages of `out` are faulted in parallel
+            # while the kernels run: the host thread pool touches one word per page of this chunk's rows of `out` -- fresh
+            # memory whose page faults (8-90 ms for 86 MB, box and moment dependent) would otherwise sit behind the copy
+            rows = out[s0:s0 + len(chunk)]
+            touch = [_hostio._threads().submit(_touch_pages, rows[r, c0:c0 + _hostio._CHUNK])
+                     for r in range(len(chunk)) for c0 in range(0, grid.n, _hostio._CHUNK)]
+            # device -> one reusable pinned block (a pageable hipMemcpy runs at a few GB/s) -> the result rows, copied by
+            # the host thread pool
             need = len(chunk) * grid.n
             pinned = _STAGE.get("buf")
             if pinned is None or pinned.numel() < need:  # kept between calls: page-locking a block of this size costs ~70 ms
@@ -98,6 +109,8 @@ def cross_section_grid(SourceTables, T, P_atm, X, WavenumberWingHW=50.0, Wavenum
             pinned[:len(chunk)].copy_(dev, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             src = pinned.numpy()
+            for f in touch:
+                f.result()
             futs = [_hostio._threads().submit(np.copyto, out[s0 + r, c0:c0 + _hostio._CHUNK], src[r, c0:c0 + _hostio._CHUNK])
                     for r in range(len(chunk)) for c0 in range(0, grid.n, _hostio._CHUNK)]
             for f in futs:

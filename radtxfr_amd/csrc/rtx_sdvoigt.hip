@@ -36,25 +36,47 @@ __device__ __forceinline__ cd cmul(cd a, cd b) { return {a.r * b.r - a.i * b.i, 
 __device__ __forceinline__ cd cadd(cd a, cd b) { return {a.r + b.r, a.i + b.i}; }
 __device__ __forceinline__ cd csub(cd a, cd b) { return {a.r - b.r, a.i - b.i}; }
 __device__ __forceinline__ cd cscale(cd a, double s) { return {a.r * s, a.i * s}; }
+// Reciprocal and square root without the library's range handling: the arguments here are sums of squares of O(1e-6 .. 1e6)
+// quantities -- never subnormal, never near overflow -- so v_rcp_f64 / v_rsq_f64 (2^-26) plus two Newton steps (<= 1 ulp, as in
+// rtx_voigt_math.h: weideman_re) replace the IEEE division sequence (div_scale / div_fmas / div_fixup) and the scaled sqrt:
+// ~8 instead of ~15 and ~30 instructions, four to six of them per profile evaluation in a kernel that is bound by fp64 issue.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_sqrt(double s) {  // s >= 0
+  const double y = __builtin_amdgcn_rsq(s);
+  double g = s * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, s), h, g);
+  return s > 0.0 ? g : 0.0;
+}
 __device__ __forceinline__ cd cinv(cd a) {
-  const double d = 1.0 / (a.r * a.r + a.i * a.i);
+  const double d = fast_rcp(a.r * a.r + a.i * a.i);
   return {a.r * d, -a.i * d};
 }
 __device__ __forceinline__ cd cdiv(cd a, cd b) { return cmul(a, cinv(b)); }
 // |a| without hypot's scaling (the arguments here are O(1e-6 .. 1e6): no overflow or underflow to guard against; the
 // library hypot costs more than the rest of the far-wing evaluation, and the 1-ulp difference is far below the 1e-9 the
 // parity tests hold this path to)
-__device__ __forceinline__ double cabs(cd a) { return sqrt(a.r * a.r + a.i * a.i); }
+__device__ __forceinline__ double cabs(cd a) { return fast_sqrt(a.r * a.r + a.i * a.i); }
 // principal square root (numpy.sqrt on complex128)
 __device__ __forceinline__ cd csqrt_(cd z) {
   const double m = cabs(z);
   if (m == 0.0) return {0.0, z.i};
   if (z.r >= 0.0) {
-    const double t = sqrt(0.5 * (m + z.r));
-    return {t, z.i / (2.0 * t)};
+    const double t = fast_sqrt(0.5 * (m + z.r));
+    return {t, z.i * fast_rcp(2.0 * t)};
   }
-  const double t = sqrt(0.5 * (m - z.r));
-  return {fabs(z.i) / (2.0 * t), copysign(t, z.i)};
+  const double t = fast_sqrt(0.5 * (m - z.r));
+  return {fabs(z.i) * fast_rcp(2.0 * t), copysign(t, z.i)};
 }
 
 // hum1_wei, misc/hapi.py:9833-9844: w(x + iy), Weideman's 24-term expansion where |x| + y < 15, else the one-term

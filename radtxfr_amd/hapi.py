@@ -63,12 +63,17 @@ def _column_signature(v, nrow):
         w = _SIG_WEIGHTS[a.size] = np.random.default_rng(12345).uniform(0.5, 1.5, a.size)
     if not a.size:
         return (0, 0.0)
-    d = float(np.dot(a, w))
+    # (np.einsum, not np.dot: the BLAS dot product is multi-threaded -- 64 OpenBLAS threads on a box whose share is 16 CPUs --
+    # and every few calls one of the 15 products stalled for 70-80 ms waking them: the sporadic slow drop-in calls of
+    # profiles/r3_time_dropin.txt with a table name / column dict, and every other afit_xs.cross_section_grid call)
+    if a.dtype != np.float64:
+        a = a.astype(np.float64)
+    d = float(np.einsum("i,i->", a, w))
     if d != d:
         # a NaN in the column (e.g. a blank field of a .par record): NaN never compares equal, which would rebuild the
         # device table on every call. Fingerprint the finite part and the positions of the NaNs instead.
         bad = np.isnan(a.astype(np.float64, copy=False))
-        return (a.size, float(np.dot(np.where(bad, 0.0, a), w)), float(np.dot(bad, w)))
+        return (a.size, float(np.einsum("i,i->", np.where(bad, 0.0, a), w)), float(np.einsum("i,i->", bad.astype(np.float64), w)))
     return (a.size, d)
 
 
