@@ -11,6 +11,7 @@ from radtxfr_amd import engine, synthetic
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=24)
+ap.add_argument("--pipes", default="1,2,3,1,2", help="pipeline counts to time, in this order")
 ap.add_argument("--shard", default="", help="R/N: rank R's cost-weighted tile-aligned shard of N (with its line subset), as bench.py --gpus N runs it")
 args = ap.parse_args()
 full = synthetic.synth_line_table(synthetic.SEED_C3, 100000, 475.0, 6025.0)
@@ -26,7 +27,7 @@ if args.shard:
     n_pts = grid.n
     print(f"shard {r} of {nw}: {grid.n} points, {full['nu'].size} lines")
 lines = engine.LineTable(full)
-for P in (1, 2, 3, 1, 2):
+for P in [int(v) for v in args.pipes.split(",")]:
     streams = [torch.cuda.Stream() for _ in range(P)]
     runs = []
     for s in streams:
