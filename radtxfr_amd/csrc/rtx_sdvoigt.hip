@@ -2,9 +2,11 @@
 // with anuVC = eta = 0, for which the common part (:10022) reduces to LS = Re(Aterm)/pi.
 //
 // The profile is a difference of two complex probability functions of nearby arguments (PART4), so it is evaluated
-// in fp64 throughout, one thread per grid point looping over the lines whose window can reach its block (gather; the
-// windows are the Voigt ones, written by the prologue). This is the cross-section generator's path, not the TUD hot
-// path: no fp32 fast path, no node levels.
+// in fp64 throughout. Default kernel (sdvoigt_tile_kernel, below): a workgroup per tile of 1024 points, far wings at
+// Chebyshev nodes (32 per tile, 12 per 64-point row), the rows around a centre and around every regime switch point by
+// point. Cross-check (sdvoigt_kernel, RADTXFR_SD_KERNEL=gather): one thread per grid point looping over the lines whose
+// window can reach its block. The windows are the Voigt ones, written by the prologue. This is the cross-section
+// generator's path (misc/RT_gen_AbsXS_files.py:90), not the TUD hot path.
 #include "rtx_common.h"
 
 #include <stdlib.h>
