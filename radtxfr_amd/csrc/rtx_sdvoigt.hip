@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void sdvoigt_kernel(SdArgs a) {
 //                per row (rho = 9: <= 1e-10), carried to the points by a 64 x 12 matrix.
 //   point by point   everything else: the <= 5 rows around the centre, the rows that hold a regime switch (|x| + y = 15 of
 //                either argument, the PART2 / PART3 thresholds) and the <= 2 rows cut by a window edge.
-// Every contribution is positive, so the sum keeps the relative bound; the parity tests hold this path to 1e-9 of the
+// Every contribution taken to a node level is positive (records with Gamma0 <= 1.5 Gamma2, whose profile can change sign, have
+// no zones and stay point by point), so the sum keeps the relative bound; the parity tests hold this path to 1e-9 of the
 // reference as before. Where the regimes switch is a closed form per line (sd_zones): with sqrt(X + Y) = p + iq the far
 // condition |x1| + y1 >= 15 reads p + |q| >= K = 15 + csqrtY, and (p + |q|)^2 = |X + Y| + |Im X| makes it
 // |Im X| >= (K^4 - R^2) / (2 K^2), R = Re X + Y. A margin of two grid points around every switch keeps the rounding of the
